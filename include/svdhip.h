@@ -1,0 +1,189 @@
+/*
+ * svdhip.h -- C ABI of libsvdhip.so: the MI355X (gfx950 / CDNA4) kernels behind the StreamingSVD
+ * denoising hot path (StreamingWrapper.forward -> ControlNet + VideoUNet(+CAM), Euler-EDM step glue,
+ * temporal VAE decode).
+ *
+ * The reference (Picsart-AI-Research/StreamingT2V) has no FFI: its "operators" are the PyTorch/xformers/cuDNN
+ * library ops its nn.Modules dispatch to.  Every entry point below replaces one such
+ * library dispatch; the reference call site is cited per function (paths relative to /root/reference/code).
+ *
+ * Contract (all entry points):
+ *   - plain pointers + sizes, no torch types; the caller owns every buffer (device memory) and the stream;
+ *   - stateless, re-entrant, asynchronous on `stream`; no allocation, no host sync inside;
+ *   - returns 0 on success, a negative SVD_E* code on bad arguments / launch failure (no exceptions);
+ *   - activations are "channels-last token" tensors: row m = (frame, pixel), contiguous channels,
+ *     explicit row stride (`ld*`, in elements).  bf16 storage, fp32 accumulation everywhere.
+ */
+#ifndef SVDHIP_H
+#define SVDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* svd_stream_t;      /* hipStream_t */
+typedef uint16_t svd_bf16;       /* raw bfloat16 bits */
+
+enum {
+    SVD_OK = 0,
+    SVD_EINVAL = -1,   /* bad shape / alignment / unsupported combination */
+    SVD_ELAUNCH = -2,  /* hip launch error */
+};
+
+/* ---- library ------------------------------------------------------------------------------------------- */
+/* ABI version of this header; bumped on any signature change. */
+int svd_abi_version(void);
+/* hipGetLastError()-style text of the last launch failure on this thread ("" if none). */
+const char* svd_last_error(void);
+
+/* ---- GEMM family (MFMA bf16, fp32 accumulate) ------------------------------------------------------------
+ * C[M,N] = epilogue( A_view[M,K] . W[N,K]^T )
+ * Replaces: every nn.Linear (cuBLAS addmm; models/svd/sgm/modules/attention.py:94-120,262-351),
+ *           nn.Conv2d 3x3 / 1x1 (cuDNN; models/svd/sgm/modules/diffusionmodules/openaimodel.py:257-314,134-137,192-199),
+ *           nn.Conv3d (3,1,1) of VideoResBlock.time_stack (models/diffusion/video_model.py:46-59),
+ *           F.interpolate(nearest, 2x) feeding Upsample.conv (openaimodel.py:139-157).
+ * A_view modes (implicit GEMM, nothing is materialised):
+ *   SVD_A_PLAIN    : row m of A, K contiguous.
+ *   SVD_A_CONV3X3  : m = (f, yo, xo); K = 9*cin ordered (ky, kx, c); zero padding 1; stride 1|2; optional
+ *                    nearest 2x upsample of the source (ups=1) folded into the addressing.
+ *   SVD_A_TEMPORAL3: m = (b, t, p); K = 3*cin ordered (kt, c); zero padding at t=0 and t=T-1.
+ * Epilogue, in this order (each optional):  v = acc + bias[n] + rowvec[m / rows_per_vec][n] + R[m][n];
+ *   GEGLU (W rows interleaved in blocks of 32: value|gate): v = v_value * gelu_erf(v_gate), N_out = N/2;
+ *   blend: v = alpha * S[m][n] + (1 - alpha) * v;   SiLU: v = silu(v).
+ * Output: bf16 row-major (ldc), or fp32 row-major, or bf16 "transposed per frame" C[f][n][tok] (ld = tokens_ld)
+ *   used to hand V^T to the attention kernels.
+ */
+enum { SVD_A_PLAIN = 0, SVD_A_CONV3X3 = 1, SVD_A_TEMPORAL3 = 2 };
+enum { SVD_OUT_BF16 = 0, SVD_OUT_F32 = 1, SVD_OUT_BF16_T = 2 };
+enum { SVD_EPI_GEGLU = 1, SVD_EPI_SILU = 2 /* v = silu(v) last (ControlNet cond-embedding conv_in, controlnet.py:105-106) */ };
+
+typedef struct svd_gemm_args {
+    /* operands */
+    const svd_bf16* A;  int64_t lda;      /* activation rows, stride in elements */
+    const svd_bf16* W;  int64_t ldw;      /* weights [N][K] row-major */
+    int32_t M, N, K;
+    /* A view */
+    int32_t a_mode;
+    int32_t cin;                          /* conv / temporal: channels per tap (K = taps*cin) */
+    int32_t hin, win;                     /* conv: source frame size (before optional upsample) */
+    int32_t hout, wout;                   /* conv: output frame size; M = frames*hout*wout */
+    int32_t stride, ups;                  /* conv: stride 1|2 ; ups 0|1 (nearest 2x upsample of source) */
+    int32_t t_frames, rows_per_frame;     /* temporal: T and pixels per frame */
+    const svd_bf16* zeros;                /* >= 128 B of zeros (source of padded taps) */
+    /* epilogue */
+    const float* bias;                    /* [N] or NULL */
+    const float* rowvec; int32_t rowvec_ld; int32_t rows_per_vec;  /* per-frame vector add, or NULL */
+    const svd_bf16* R;  int64_t ldr;      /* residual, or NULL */
+    const svd_bf16* S;  int64_t lds;      /* blend partner, or NULL */
+    float alpha;
+    int32_t epi_flags;
+    /* output */
+    void* C; int64_t ldc;
+    int32_t out_mode;
+    int32_t tok_per_frame; int64_t tokens_ld;  /* SVD_OUT_BF16_T only */
+    /* tuning: 0 = heuristic, else explicit tile config id (see svd_gemm_num_configs) */
+    int32_t tile_cfg;
+} svd_gemm_args;
+
+int svd_gemm(const svd_gemm_args* args, svd_stream_t stream);
+int svd_gemm_num_configs(void);
+/* fills bm/bn of config id (1-based); returns 0 or SVD_EINVAL */
+int svd_gemm_config_info(int cfg, int* bm, int* bn, int* threads, int* lds_bytes);
+
+/* ---- attention ------------------------------------------------------------------------------------------
+ * Spatial self-attention, head dim 64, flash-style (scores never materialised).
+ * Replaces xformers.memory_efficient_attention / F.scaled_dot_product_attention in
+ * models/svd/sgm/modules/attention.py:339-343,434-441 (BasicTransformerBlock.attn1).
+ *   Q,K : [frames][n_tok][heads][64] with row stride ldq/ldk (elements) between tokens, frame stride = n_tok*ld
+ *   Vt  : [frames][heads*64][tok_ld]   (V transposed per frame; produced by svd_gemm SVD_OUT_BF16_T)
+ *   O   : [frames][n_tok][heads][64], row stride ldo
+ * scale = 1/sqrt(64) applied inside.
+ */
+int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
+                         const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
+                         int32_t frames, int32_t n_tok, int32_t heads, svd_stream_t stream);
+
+/* Per-pixel temporal attention over short sequences (<= 32), head dim 64.
+ * Replaces the attention inside VideoTransformerBlock.attn1 (models/svd/sgm/modules/video_attention.py:145-148,
+ * on the "(b t) s c -> (b s) t c" view, never materialised here) and the diffusers Attention of the CAM
+ * merger (models/cam/conditioning.py:65-68; q 25 frames, kv 7 ControlNet frames).
+ *   Q : rows (b, tq, p) -> Q + ((b*Tq + tq)*n_pix + p)*ldq ; K,V likewise with Tk ; O like Q.
+ */
+int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
+                          const svd_bf16* V, int64_t ldv, svd_bf16* O, int64_t ldo,
+                          int32_t batch, int32_t tq, int32_t tk, int32_t n_pix, int32_t heads,
+                          svd_stream_t stream);
+
+/* Row softmax: P[r][0..n) = softmax(scale * S[r][0..n)) ; fp32 in, bf16 out (VAE AttnBlock, model.py:180-201). */
+int svd_softmax_rows(const float* S, int64_t lds, svd_bf16* P, int64_t ldp, int64_t rows, int32_t n,
+                     float scale, svd_stream_t stream);
+
+/* ---- normalisation --------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) on channels-last data, statistics in fp32 over (frames_per_stat frames x pixels x C/G).
+ * Replaces GroupNorm32 / nn.GroupNorm (+ the following SiLU) of
+ * models/svd/sgm/modules/diffusionmodules/util.py:259-276, openaimodel.py:257-261,292-305, attention.py:132-135,
+ * models/cam/conditioning.py:33-34,57-59 (5-D statistics: frames_per_stat = T).
+ *   stats: workspace, float [frames/frames_per_stat][groups][2] (mean, rstd) written by svd_groupnorm_stats.
+ *   partial: workspace float, >= svd_groupnorm_partial_elems(...) elements.
+ */
+int64_t svd_groupnorm_partial_elems(int32_t frames, int32_t channels);
+int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
+                        int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats,
+                        svd_stream_t stream);
+int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
+                        int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
+                        const float* gamma, const float* beta, int32_t silu, svd_stream_t stream);
+
+/* LayerNorm over channels per token (eps 1e-5), optional per-frame vector added first (x + vec[frame]) with the
+ * sum also written to Xsum (used for "x_mix = x + time_pos_embed" video_attention.py:318-321), optional SiLU
+ * (ControlNetConditioningEmbedding per-pixel LN + SiLU, models/control/controlnet.py:108-114).
+ * Replaces nn.LayerNorm of attention.py:528-530, video_attention.py:59,87,101-102.
+ */
+int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
+                  const float* gamma, const float* beta, float eps,
+                  const float* addvec, int32_t addvec_ld, int32_t rows_per_vec, svd_bf16* Xsum, int64_t ldxsum,
+                  int32_t silu, svd_stream_t stream);
+
+/* ---- layout / elementwise glue ---------------------------------------------------------------------------- */
+/* NCHW fp32 (two sources concatenated on C: c0 from X0, c1 from X1, X1 may be NULL) -> channels-last bf16 with
+ * channel padding to cpad, scaled per frame by scale[f] (NULL = 1).  (wrappers.py:33 concat + Denoiser c_in) */
+int svd_nchw_to_tokens(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
+                       svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, svd_stream_t stream);
+/* channels-last (bf16 or fp32, first c channels of rows with stride ld) -> NCHW fp32 */
+int svd_tokens_to_nchw(const void* X, int32_t x_is_f32, int64_t ldx, float* Y, int32_t c, int32_t frames,
+                       int32_t pix, svd_stream_t stream);
+/* Y[m][0..ca) = A[m], Y[m][ca..ca+cb) = B[m]   (th.cat([h, hs.pop()], dim=1), video_model.py:608) */
+int svd_concat_channels(const svd_bf16* A, int64_t lda, int32_t ca, const svd_bf16* B, int64_t ldb, int32_t cb,
+                        svd_bf16* Y, int64_t ldy, int64_t rows, svd_stream_t stream);
+/* Y = X + B (row-wise, same shape)  (Merger addition, controlnet.py:41-42) */
+int svd_add_rows(const svd_bf16* X, int64_t ldx, const svd_bf16* B, int64_t ldb, svd_bf16* Y, int64_t ldy,
+                 int64_t rows, int32_t channels, svd_stream_t stream);
+/* y = silu(x) on fp32 vectors (emb_layers' leading SiLU, openaimodel.py:284-290) -> bf16 */
+int svd_silu_f32_to_bf16(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, svd_stream_t stream);
+/* sinusoidal embedding [cos | sin], freqs = exp(-ln(max_period) * i / half)  (util.py:207-231) -> bf16 [n][dim] */
+int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, svd_bf16* Y,
+                           svd_stream_t stream);
+
+/* ---- sampler glue (Denoiser + LinearPredictionGuider + Euler step) ------------------------------------------
+ * One Euler-EDM step tail on the fp32 NCHW state x[T][C][pix]:
+ *   den_{u,c} = net_{u,c} * c_out + x * c_skip          (denoiser.py:36-39)
+ *   den = den_u + scale[t] * (den_c - den_u)             (guiders.py:78-86)
+ *   d = (x - den) / sigma ; x += d * (sigma_next - sigma) (sampling.py:100-103, sampling_utils.py:34-35)
+ * net: channels-last fp32 [2T][pix][ldn] (uncond frames first).
+ */
+int svd_edm_euler_step(float* x, const float* net, int64_t ldn, const float* guidance_scale, int32_t T,
+                       int32_t C, int32_t pix, float sigma, float sigma_next, svd_stream_t stream);
+
+/* ---- VAE tail -------------------------------------------------------------------------------------------
+ * AE3DConv.time_mix_conv: Conv3d(3->3,(3,1,1)) over frames of the 3-channel image + clamp(-1,1) optional,
+ * channels-last fp32 in (ld), NCHW fp32 out.  (temporal_ae.py:99-105, streaming_svd.py:220)
+ */
+int svd_ae_time_mix3(const float* X, int64_t ldx, const float* w /*[3][3][3] (co,ci,kt)*/, const float* b,
+                     float* Y, int32_t frames, int32_t pix, int32_t clamp, svd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDHIP_H */

@@ -1,0 +1,71 @@
+"""Seeded test cases shared by oracle/make_golden.py (reference side) and tests/ (oracle + HIP side).
+
+TEST INFRASTRUCTURE.  Inputs are re-derived from fixed seeds so that only reference OUTPUTS need to be stored
+under tests/golden/.  Sizes: the smallest configuration that still exercises every kernel path -- the ControlNet
+hard-codes model_channels = 320 (controlnet.py:443-446), so "tiny" shrinks depth/levels/frames/pixels instead.
+"""
+import torch
+
+TINY_UNET = dict(num_res_blocks=1, attention_resolutions=(2, 1), channel_mult=(1, 2), cond_embed=(32, 96, 256, 512),
+                 T=8, Tc=3, h=16, w=16)
+TINY_VAE = dict(ch=32, ch_mult=(1, 2), num_res_blocks=1, T=4, h=8, w=8)
+
+
+def _common_unet_kwargs():
+    return dict(in_channels=8, model_channels=320, out_channels=4, num_conditional_frames=None, dropout=0.0,
+                conv_resample=True, dims=2, num_classes="sequential", use_checkpoint=False, num_heads=-1,
+                num_head_channels=64, num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                transformer_depth=1, transformer_depth_middle=None, context_dim=1024, time_downup=False,
+                time_context_dim=None, extra_ff_mix_layer=True, use_spatial_context=True,
+                merge_strategy="learned_with_images", merge_factor=0.5, spatial_transformer_attn_type="softmax",
+                video_kernel_size=[3, 1, 1], use_linear_in_transformer=True, adm_in_channels=768,
+                disable_temporal_crossattention=False, max_ddpm_temb_period=10000,
+                merging_mode="attention_cross_attention", controlnet_mode=True, use_apm=False)
+
+
+def tiny_unet_kwargs():
+    """Constructor kwargs of the reference VideoUNet (config.yaml:69-115) shrunk to the tiny case."""
+    kw = _common_unet_kwargs()
+    kw.update(num_res_blocks=TINY_UNET["num_res_blocks"], attention_resolutions=list(TINY_UNET["attention_resolutions"]),
+              channel_mult=list(TINY_UNET["channel_mult"]))
+    return kw
+
+
+def full_unet_kwargs():
+    kw = _common_unet_kwargs()
+    kw.update(num_res_blocks=2, attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4])
+    return kw
+
+
+def _gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def tiny_wrapper_inputs():
+    g = _gen(1234)
+    T, h, w = TINY_UNET["T"], TINY_UNET["h"], TINY_UNET["w"]
+    F = 2 * T
+    return dict(
+        x=torch.randn(F, 4, h, w, generator=g),
+        t=torch.randn(F, generator=g) * 0.5,
+        concat=torch.randn(F, 4, h, w, generator=g) * 0.5,
+        crossattn=torch.randn(F, 1, 1024, generator=g),
+        vector=torch.randn(F, 768, generator=g) * 0.5,
+        ctrl_frames=torch.rand(1, TINY_UNET["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1,
+    )
+
+
+def tiny_sampler_inputs():
+    g = _gen(4321)
+    T, h, w = TINY_UNET["T"], TINY_UNET["h"], TINY_UNET["w"]
+    c = dict(concat=torch.randn(T, 4, h, w, generator=g) * 0.5, crossattn=torch.randn(T, 1, 1024, generator=g),
+             vector=torch.randn(T, 768, generator=g) * 0.5)
+    uc = dict(concat=torch.zeros(T, 4, h, w), crossattn=torch.zeros(T, 1, 1024), vector=c["vector"].clone())
+    return dict(noise=torch.randn(T, 4, h, w, generator=g), c=c, uc=uc)
+
+
+def tiny_vae_inputs():
+    g = _gen(99)
+    return dict(z=torch.randn(TINY_VAE["T"], 4, TINY_VAE["h"], TINY_VAE["w"], generator=g))

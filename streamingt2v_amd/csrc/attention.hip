@@ -1,0 +1,388 @@
+// Attention kernels for gfx950 (head dim 64 everywhere in the StreamingSVD UNet / ControlNet / CAM).
+#include "svd_common.h"
+
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    bf16x2_t t;
+    t[0] = (__bf16)a; t[1] = (__bf16)b;      // hipcc selects v_cvt_pk_bf16_f32 on gfx950
+    return __builtin_bit_cast(uint32_t, t);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Spatial self-attention, flash style.  One workgroup = NW waves x 32 query rows; KV tiles of 64 keys.
+//   S^T[key][query] = K . Q^T        (A = K rows from LDS, B = Q rows held in registers)
+//   -> a lane owns ONE query column: online softmax is lane-local (+1 cross-half exchange for the row max).
+//   O^T[d][query]  += V^T . P^T      (A = V^T rows (keys contiguous) from LDS, B = P from the S^T registers)
+//   -> P never leaves registers: the keys of a 32-key block are permuted (bits 2<->3 of the LDS row index) while
+//      staging K so that accumulator registers 8s..8s+7 of a lane are 8 CONSECUTIVE keys, i.e. exactly the
+//      B-operand fragment of the PV MFMA, matched by one ds_read_b128 of V^T.
+// K and V^T tiles are staged with global_load_lds; swizzle (slot ^= (row>>1)&7) on source address and on read.
+// ------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
+    const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
+    const svd_bf16* __restrict__ Vt, int64_t tok_ld, svd_bf16* __restrict__ O, int64_t ldo,
+    int frames, int n_tok, int heads, int qblocks) {
+    constexpr int NT = NW * 64;
+    constexpr int BQ = NW * 32;
+    constexpr int KT = 64;                 // keys per tile
+    constexpr int TILE_B = KT * 128;       // 8 KiB : [64 rows][64 bf16]
+    constexpr int RPP = NT / 8;            // tile rows staged per pass
+    constexpr int PASSES = 64 / RPP;       // 2 (NW=4) or 1 (NW=8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K tile + Vt tile)
+    const uint32_t smem_base = lds_addr_of(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware block order: all query blocks of one (frame, head) stay on one XCD (K/V reuse in its L2).
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int fh = wgid / qblocks, qb = wgid - fh * qblocks;
+    const int f = fh / heads, h = fh - f * heads;
+
+    const svd_bf16* Qf = Q + (int64_t)f * n_tok * ldq + h * 64;
+    const svd_bf16* Kf = K + (int64_t)f * n_tok * ldk + h * 64;
+    const svd_bf16* Vf = Vt + ((int64_t)f * heads + h) * 64 * tok_ld;
+
+    // Q fragments (B operand): lane -> query l31, d = 16*ks + 8*hi .. +8
+    int qrow = qb * BQ + wave * 32 + l31;
+    const bool q_valid = qrow < n_tok;
+    if (!q_valid) qrow = n_tok - 1;
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(Qf + (int64_t)qrow * ldq + 16 * ks + 8 * hi);
+
+    // staging coordinates
+    const int srow = tid >> 3, ps = tid & 7;
+    const int ls = ps ^ ((srow >> 1) & 7);
+    auto stage = [&](int kv0, int buf) {
+        const uint32_t dK = __builtin_amdgcn_readfirstlane(smem_base + buf * (2 * TILE_B) + wave * 1024);
+        const uint32_t dV = dK + TILE_B;
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            const int r = j * RPP + srow;                                   // LDS row
+            const int kperm = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);  // key held by this row (bits 2<->3)
+            int key = kv0 + kperm;
+            if (key > n_tok - 1) key = n_tok - 1;
+            glds16_asm(Kf + (int64_t)key * ldk + ls * 8, dK + j * (NT * 16));
+            glds16_asm(Vf + (int64_t)r * tok_ld + kv0 + ls * 8, dV + j * (NT * 16));
+        }
+    };
+
+    f32x16_t o_acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o_acc[0][i] = 0.f; o_acc[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = 0.125f * 1.44269504088896341f;   // d^-0.5 * log2(e)
+
+    const int ntiles = (n_tok + KT - 1) / KT;
+    stage(0, 0);
+    svd_wait_dma();
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage((t + 1) * KT, cur ^ 1);
+        const char* sK = smem + cur * (2 * TILE_B);
+        const char* sV = sK + TILE_B;
+
+        // ---- S^T = K Q^T ----
+        f32x16_t s_acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s_acc[0][i] = 0.f; s_acc[1][i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int lslot = 2 * ks + hi;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int row = kb * 32 + l31;
+                const uint4 kf = *(const uint4*)(sK + row * 128 + ((lslot ^ ((row >> 1) & 7)) << 4));
+                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s_acc[kb], 0, 0, 0);
+            }
+        }
+        // mask keys beyond n_tok (last tile only).  register r of block kb, half hi <-> key
+        //   kv0 + 32*kb + (r&7) + 8*hi + 16*(r>>3)
+        const int kv0 = t * KT;
+        if (kv0 + KT > n_tok) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * kb + (r & 7) + 8 * hi + 16 * (r >> 3);
+                    if (key >= n_tok) s_acc[kb][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (lane-local row) ----
+        float mx = s_acc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        uint32_t pk[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s_acc[kb][r] * c - m_new);
+                const float p1 = __builtin_amdgcn_exp2f(s_acc[kb][r + 1] * c - m_new);
+                psum += p0 + p1;
+                pk[kb][r >> 1] = cvt_pk_bf16(p0, p1);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o_acc[0][i] *= alpha; o_acc[1][i] *= alpha; }
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int lslot = 2 * s + hi;
+            uint4 pf;
+            pf.x = pk[s >> 1][4 * (s & 1) + 0]; pf.y = pk[s >> 1][4 * (s & 1) + 1];
+            pf.z = pk[s >> 1][4 * (s & 1) + 2]; pf.w = pk[s >> 1][4 * (s & 1) + 3];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + l31;
+                const uint4 vf = *(const uint4*)(sV + row * 128 + ((lslot ^ ((row >> 1) & 7)) << 4));
+                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf), o_acc[db], 0, 0, 0);
+            }
+        }
+        svd_wait_dma();
+        __syncthreads();
+    }
+
+    // ---- finalize & store: lane holds query l31, d = 32*db + 8*g + 4*hi + (0..3) ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q_valid) {
+        svd_bf16* Orow = O + ((int64_t)f * n_tok + qrow) * ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 o;
+                o.x = cvt_pk_bf16(o_acc[db][4 * g + 0] * inv, o_acc[db][4 * g + 1] * inv);
+                o.y = cvt_pk_bf16(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv);
+                *(uint2*)(Orow + 32 * db + 8 * g + 4 * hi) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Per-pixel temporal attention (sequence <= 32 frames), head dim 64.  HBM-bound: q/k/v are read once, in place,
+// from the (frame, pixel, channel) token layout -- the reference's "(b t) s c -> (b s) t c" transposes never
+// happen.  One half-wave (32 lanes) per (batch, pixel, head): lane i holds query i in fp32 registers; K and V of
+// the problem sit in LDS (bf16) and are read as wave-broadcast 16-byte vectors.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TA_MAXT = 32;
+__global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
+    const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
+    const svd_bf16* __restrict__ V, int64_t ldv, svd_bf16* __restrict__ O, int64_t ldo,
+    int batch, int tq, int tk, int n_pix, int heads, int64_t n_prob) {
+    __shared__ __attribute__((aligned(16))) uint16_t sKV[8][2][TA_MAXT][64];   // 64 KiB
+    const int tid = threadIdx.x;
+    const int hw = tid >> 5;            // half-wave 0..7
+    const int li = tid & 31;
+    const float c = 0.125f;
+
+    for (int64_t base = (int64_t)blockIdx.x * 8; base < n_prob; base += (int64_t)gridDim.x * 8) {
+        const int64_t prob = base + hw;
+        const bool active = prob < n_prob;
+        // problem index -> (b, p, h) with h fastest: the 8 half-waves of a block read adjacent channels/pixels
+        int b = 0, pp = 0, h = 0;
+        if (active) {
+            h = (int)(prob % heads);
+            const int64_t bp = prob / heads;
+            pp = (int)(bp % n_pix); b = (int)(bp / n_pix);
+        }
+        __syncthreads();   // previous iteration's LDS reads done
+        if (active) {
+            // stage K,V: tk rows x 128 B each = tk*8 16-byte vectors per matrix, spread over the 32 lanes
+            for (int v = li; v < tk * 8; v += 32) {
+                const int j = v >> 3, sl = v & 7;
+                const int64_t row = ((int64_t)b * tk + j) * n_pix + pp;
+                *(uint4*)&sKV[hw][0][j][sl * 8] = *(const uint4*)(K + row * ldk + h * 64 + sl * 8);
+                *(uint4*)&sKV[hw][1][j][sl * 8] = *(const uint4*)(V + row * ldv + h * 64 + sl * 8);
+            }
+        }
+        float q[64];
+        const bool qact = active && li < tq;
+        {
+            const int qi = li < tq ? li : tq - 1;
+            const int64_t row = ((int64_t)b * tq + qi) * n_pix + pp;
+            const svd_bf16* qp = Q + row * ldq + h * 64;
+#pragma unroll
+            for (int d = 0; d < 64; d += 8) {
+                uint4 u = active ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+                q[d + 0] = bf16lo_to_f32(u.x); q[d + 1] = bf16hi_to_f32(u.x);
+                q[d + 2] = bf16lo_to_f32(u.y); q[d + 3] = bf16hi_to_f32(u.y);
+                q[d + 4] = bf16lo_to_f32(u.z); q[d + 5] = bf16hi_to_f32(u.z);
+                q[d + 6] = bf16lo_to_f32(u.w); q[d + 7] = bf16hi_to_f32(u.w);
+            }
+        }
+        __syncthreads();
+        // scores
+        float s[TA_MAXT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TA_MAXT; ++j) {
+            if (j < tk) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int d = 0; d < 64; d += 8) {
+                    const uint4 u = *(const uint4*)&sKV[hw][0][j][d];
+                    a0 += q[d + 0] * bf16lo_to_f32(u.x); a1 += q[d + 1] * bf16hi_to_f32(u.x);
+                    a2 += q[d + 2] * bf16lo_to_f32(u.y); a3 += q[d + 3] * bf16hi_to_f32(u.y);
+                    a0 += q[d + 4] * bf16lo_to_f32(u.z); a1 += q[d + 5] * bf16hi_to_f32(u.z);
+                    a2 += q[d + 6] * bf16lo_to_f32(u.w); a3 += q[d + 7] * bf16hi_to_f32(u.w);
+                }
+                s[j] = ((a0 + a1) + (a2 + a3)) * c;
+                mx = fmaxf(mx, s[j]);
+            } else s[j] = -INFINITY;
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < TA_MAXT; ++j) {
+            if (j < tk) { s[j] = __expf(s[j] - mx); l += s[j]; }
+        }
+        const float inv = 1.f / l;
+        // output (reuse q registers as accumulators)
+#pragma unroll
+        for (int d = 0; d < 64; ++d) q[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TA_MAXT; ++j) {
+            if (j < tk) {
+                const float pj = s[j] * inv;
+#pragma unroll
+                for (int d = 0; d < 64; d += 8) {
+                    const uint4 u = *(const uint4*)&sKV[hw][1][j][d];
+                    q[d + 0] += pj * bf16lo_to_f32(u.x); q[d + 1] += pj * bf16hi_to_f32(u.x);
+                    q[d + 2] += pj * bf16lo_to_f32(u.y); q[d + 3] += pj * bf16hi_to_f32(u.y);
+                    q[d + 4] += pj * bf16lo_to_f32(u.z); q[d + 5] += pj * bf16hi_to_f32(u.z);
+                    q[d + 6] += pj * bf16lo_to_f32(u.w); q[d + 7] += pj * bf16hi_to_f32(u.w);
+                }
+            }
+        }
+        if (qact) {
+            const int64_t row = ((int64_t)b * tq + li) * n_pix + pp;
+            svd_bf16* op = O + row * ldo + h * 64;
+#pragma unroll
+            for (int d = 0; d < 64; d += 8) {
+                uint4 u;
+                u.x = cvt_pk_bf16(q[d + 0], q[d + 1]); u.y = cvt_pk_bf16(q[d + 2], q[d + 3]);
+                u.z = cvt_pk_bf16(q[d + 4], q[d + 5]); u.w = cvt_pk_bf16(q[d + 6], q[d + 7]);
+                *(uint4*)(op + d) = u;
+            }
+        }
+    }
+}
+
+// Row softmax, fp32 scores -> bf16 probabilities.  One workgroup per row; row cached in registers (n <= 16384).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_,
+                                                           svd_bf16* __restrict__ P, int64_t ldp, int n, float scale) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const float* s = S + r * lds_;
+    svd_bf16* p = P + r * ldp;
+    constexpr int MAXV = 16;   // 256 threads * 4 floats * 16 = 16384
+    float4 v[MAXV];
+    const int nv = n >> 2;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < nv) {
+            v[i] = *(const float4*)(s + idx * 4);
+            mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        }
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const float c = scale * 1.44269504088896341f;
+    const float mc = mx * c;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < nv) {
+            v[i].x = __builtin_amdgcn_exp2f(v[i].x * c - mc); v[i].y = __builtin_amdgcn_exp2f(v[i].y * c - mc);
+            v[i].z = __builtin_amdgcn_exp2f(v[i].z * c - mc); v[i].w = __builtin_amdgcn_exp2f(v[i].w * c - mc);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < nv) {
+            uint2 o;
+            o.x = cvt_pk_bf16(v[i].x * inv, v[i].y * inv); o.y = cvt_pk_bf16(v[i].z * inv, v[i].w * inv);
+            *(uint2*)(p + idx * 4) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
+                                    const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
+                                    int32_t frames, int32_t n_tok, int32_t heads, svd_stream_t stream) {
+    if (!Q || !K || !Vt || !O || frames <= 0 || n_tok <= 0 || heads <= 0) return SVD_EINVAL;
+    if (ldq % 8 || ldk % 8 || tok_ld % 8 || ldo % 4) return SVD_EINVAL;
+    if (tok_ld < ((n_tok + 63) / 64) * 64) return SVD_EINVAL;   // V^T rows must cover whole 64-key tiles
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt) & 15) return SVD_EINVAL;
+    constexpr int NW = 4;
+    const int qblocks = (n_tok + NW * 32 - 1) / (NW * 32);
+    const int64_t nwg = (int64_t)frames * heads * qblocks;
+    if (nwg > 0x7fffffff) return SVD_EINVAL;
+    hipLaunchKernelGGL(attn_spatial_d64_kernel<NW>, dim3((unsigned)nwg), dim3(NW * 64), 4 * 8192, (hipStream_t)stream,
+                       Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_tok, heads, qblocks);
+    SVD_CHECK_LAUNCH("attn_spatial_d64");
+    return SVD_OK;
+}
+
+extern "C" int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
+                                     const svd_bf16* V, int64_t ldv, svd_bf16* O, int64_t ldo,
+                                     int32_t batch, int32_t tq, int32_t tk, int32_t n_pix, int32_t heads,
+                                     svd_stream_t stream) {
+    if (!Q || !K || !V || !O || batch <= 0 || n_pix <= 0 || heads <= 0) return SVD_EINVAL;
+    if (tq <= 0 || tk <= 0 || tq > TA_MAXT || tk > TA_MAXT) return SVD_EINVAL;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return SVD_EINVAL;
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return SVD_EINVAL;
+    const int64_t n_prob = (int64_t)batch * n_pix * heads;
+    int64_t blocks = (n_prob + 7) / 8;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(attn_temporal_d64_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob);
+    SVD_CHECK_LAUNCH("attn_temporal_d64");
+    return SVD_OK;
+}
+
+extern "C" int svd_softmax_rows(const float* S, int64_t lds_, svd_bf16* P, int64_t ldp, int64_t rows, int32_t n,
+                                float scale, svd_stream_t stream) {
+    if (!S || !P || rows <= 0 || n <= 0 || n % 4 || n > 16384 || lds_ % 4 || ldp % 4) return SVD_EINVAL;
+    if (rows > 0x7fffffff) return SVD_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, lds_, P, ldp, n,
+                       scale);
+    SVD_CHECK_LAUNCH("softmax_rows");
+    return SVD_OK;
+}

@@ -1,0 +1,227 @@
+// Layout conversion and small fused elementwise kernels (HBM-bound glue around the MFMA kernels).
+#include "svd_common.h"
+
+namespace {
+
+// NCHW fp32 (X0 | X1 on the channel axis) -> channels-last bf16 rows of cpad channels, scaled per frame.
+__global__ void nchw_to_tokens_kernel(const float* __restrict__ X0, int c0, const float* __restrict__ X1, int c1,
+                                      const float* __restrict__ scale, svd_bf16* __restrict__ Y, int cpad, int frames, int pix) {
+    const int64_t total = (int64_t)frames * pix;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / pix), p = (int)(i - (int64_t)f * pix);
+        const float sc = scale ? scale[f] : 1.f;
+        svd_bf16* y = Y + i * cpad;
+        for (int cb = 0; cb < cpad; cb += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = cb + k;
+                float x = 0.f;
+                if (c < c0) x = X0[((int64_t)f * c0 + c) * pix + p] * sc;
+                else if (c < c0 + c1) x = X1[((int64_t)f * c1 + (c - c0)) * pix + p];
+                v[k] = x;
+            }
+            uint4 w;
+            w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
+            w.z = pack_bf16x2(v[4], v[5]); w.w = pack_bf16x2(v[6], v[7]);
+            *(uint4*)(y + cb) = w;
+        }
+    }
+}
+
+__global__ void tokens_to_nchw_kernel(const void* __restrict__ X, int is_f32, int64_t ldx, float* __restrict__ Y, int c,
+                                      int frames, int pix) {
+    const int64_t total = (int64_t)frames * pix;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / pix), p = (int)(i - (int64_t)f * pix);
+        for (int k = 0; k < c; ++k) {
+            const float v = is_f32 ? ((const float*)X)[i * ldx + k] : bf16_to_f32(((const svd_bf16*)X)[i * ldx + k]);
+            Y[((int64_t)f * c + k) * pix + p] = v;
+        }
+    }
+}
+
+// generic strided row copy of 16-byte vectors: Y[m][off..off+c) = A[m][0..c)
+__global__ void copy_rows_kernel(const svd_bf16* __restrict__ A, int64_t lda, int c, svd_bf16* __restrict__ Y, int64_t ldy,
+                                 int64_t rows) {
+    const int oct = c >> 3;
+    const int64_t total = rows * oct;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / oct;
+        const int o = (int)(i - r * oct);
+        *(uint4*)(Y + r * ldy + o * 8) = *(const uint4*)(A + r * lda + o * 8);
+    }
+}
+
+__global__ void add_rows_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const svd_bf16* __restrict__ B, int64_t ldb,
+                                svd_bf16* __restrict__ Y, int64_t ldy, int64_t rows, int c) {
+    const int oct = c >> 3;
+    const int64_t total = rows * oct;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / oct;
+        const int o = (int)(i - r * oct);
+        const uint4 a = *(const uint4*)(X + r * ldx + o * 8), b = *(const uint4*)(B + r * ldb + o * 8);
+        uint4 w;
+        w.x = pack_bf16x2(bf16lo_to_f32(a.x) + bf16lo_to_f32(b.x), bf16hi_to_f32(a.x) + bf16hi_to_f32(b.x));
+        w.y = pack_bf16x2(bf16lo_to_f32(a.y) + bf16lo_to_f32(b.y), bf16hi_to_f32(a.y) + bf16hi_to_f32(b.y));
+        w.z = pack_bf16x2(bf16lo_to_f32(a.z) + bf16lo_to_f32(b.z), bf16hi_to_f32(a.z) + bf16hi_to_f32(b.z));
+        w.w = pack_bf16x2(bf16lo_to_f32(a.w) + bf16lo_to_f32(b.w), bf16hi_to_f32(a.w) + bf16hi_to_f32(b.w));
+        *(uint4*)(Y + r * ldy + o * 8) = w;
+    }
+}
+
+__global__ void silu_f32_to_bf16_kernel(const float* __restrict__ X, svd_bf16* __restrict__ Y, int64_t n, int apply) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = X[i];
+        Y[i] = f32_to_bf16(apply ? silu_f(x) : x);
+    }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, int dim, float log_max_period,
+                                          svd_bf16* __restrict__ Y) {
+    const int half = dim >> 1;
+    const int64_t total = (int64_t)n * half;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / half), k = (int)(i - (int64_t)r * half);
+        const float freq = expf(-log_max_period * (float)k / (float)half);
+        const float a = t[r] * freq;
+        Y[(int64_t)r * dim + k] = f32_to_bf16(cosf(a));
+        Y[(int64_t)r * dim + half + k] = f32_to_bf16(sinf(a));
+        if ((dim & 1) && k == 0) Y[(int64_t)r * dim + dim - 1] = 0;
+    }
+}
+
+__global__ void edm_euler_step_kernel(float* __restrict__ x, const float* __restrict__ net, int64_t ldn,
+                                      const float* __restrict__ gscale, int T, int C, int pix, float sigma, float sigma_next) {
+    const float s2 = sigma * sigma + 1.0f;
+    const float c_skip = 1.0f / s2;
+    const float c_out = -sigma / sqrtf(s2);
+    const float dt = sigma_next - sigma;
+    const int64_t total = (int64_t)T * pix;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / pix), p = (int)(i - (int64_t)t * pix);
+        const float g = gscale[t];
+        const float* nu = net + ((int64_t)t * pix + p) * ldn;
+        const float* nc = net + ((int64_t)(T + t) * pix + p) * ldn;
+        for (int c = 0; c < C; ++c) {
+            float* xp = x + ((int64_t)t * C + c) * pix + p;
+            const float xv = *xp;
+            const float du = nu[c] * c_out + xv * c_skip;
+            const float dc = nc[c] * c_out + xv * c_skip;
+            const float den = du + g * (dc - du);
+            const float d = (xv - den) / sigma;
+            *xp = xv + d * dt;
+        }
+    }
+}
+
+__global__ void ae_time_mix3_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ w,
+                                    const float* __restrict__ b, float* __restrict__ Y, int frames, int pix, int clamp) {
+    __shared__ float sw[27 + 3];
+    if (threadIdx.x < 27) sw[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x < 3) sw[27 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    const int64_t total = (int64_t)frames * pix;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / pix), p = (int)(i - (int64_t)f * pix);
+        float o[3] = {sw[27], sw[28], sw[29]};
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const int ff = f + kt - 1;
+            if (ff < 0 || ff >= frames) continue;
+            const float* xr = X + ((int64_t)ff * pix + p) * ldx;
+            const float x0 = xr[0], x1 = xr[1], x2 = xr[2];
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+                o[co] += sw[(co * 3 + 0) * 3 + kt] * x0 + sw[(co * 3 + 1) * 3 + kt] * x1 + sw[(co * 3 + 2) * 3 + kt] * x2;
+        }
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            float v = o[co];
+            if (clamp) v = fminf(1.f, fmaxf(-1.f, v));
+            Y[((int64_t)f * 3 + co) * pix + p] = v;
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t n, int bs = 256) {
+    int64_t g = (n + bs - 1) / bs;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int svd_nchw_to_tokens(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
+                                  svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, svd_stream_t stream) {
+    if (!X0 || !Y || c0 <= 0 || c1 < 0 || (c1 > 0 && !X1) || cpad % 8 || cpad < c0 + c1 || frames <= 0 || pix <= 0) return SVD_EINVAL;
+    if ((uintptr_t)Y & 15) return SVD_EINVAL;
+    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0, (hipStream_t)stream, X0, c0,
+                       X1, c1, scale, Y, cpad, frames, pix);
+    SVD_CHECK_LAUNCH("nchw_to_tokens");
+    return SVD_OK;
+}
+
+extern "C" int svd_tokens_to_nchw(const void* X, int32_t x_is_f32, int64_t ldx, float* Y, int32_t c, int32_t frames,
+                                  int32_t pix, svd_stream_t stream) {
+    if (!X || !Y || c <= 0 || frames <= 0 || pix <= 0 || ldx < c) return SVD_EINVAL;
+    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0, (hipStream_t)stream, X,
+                       x_is_f32, ldx, Y, c, frames, pix);
+    SVD_CHECK_LAUNCH("tokens_to_nchw");
+    return SVD_OK;
+}
+
+extern "C" int svd_concat_channels(const svd_bf16* A, int64_t lda, int32_t ca, const svd_bf16* B, int64_t ldb, int32_t cb,
+                                   svd_bf16* Y, int64_t ldy, int64_t rows, svd_stream_t stream) {
+    if (!A || !B || !Y || ca <= 0 || cb <= 0 || ca % 8 || cb % 8 || lda % 8 || ldb % 8 || ldy % 8 || rows <= 0) return SVD_EINVAL;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)Y) & 15) return SVD_EINVAL;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * (ca / 8))), dim3(256), 0, (hipStream_t)stream, A, lda, ca, Y, ldy, rows);
+    SVD_CHECK_LAUNCH("concat(A)");
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * (cb / 8))), dim3(256), 0, (hipStream_t)stream, B, ldb, cb, Y + ca, ldy, rows);
+    SVD_CHECK_LAUNCH("concat(B)");
+    return SVD_OK;
+}
+
+extern "C" int svd_add_rows(const svd_bf16* X, int64_t ldx, const svd_bf16* B, int64_t ldb, svd_bf16* Y, int64_t ldy,
+                            int64_t rows, int32_t channels, svd_stream_t stream) {
+    if (!X || !B || !Y || channels <= 0 || channels % 8 || ldx % 8 || ldb % 8 || ldy % 8 || rows <= 0) return SVD_EINVAL;
+    if (((uintptr_t)X | (uintptr_t)B | (uintptr_t)Y) & 15) return SVD_EINVAL;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (channels / 8))), dim3(256), 0, (hipStream_t)stream, X, ldx, B, ldb, Y,
+                       ldy, rows, channels);
+    SVD_CHECK_LAUNCH("add_rows");
+    return SVD_OK;
+}
+
+extern "C" int svd_silu_f32_to_bf16(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, svd_stream_t stream) {
+    if (!X || !Y || n <= 0) return SVD_EINVAL;
+    hipLaunchKernelGGL(silu_f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, X, Y, n, apply_silu);
+    SVD_CHECK_LAUNCH("silu_f32_to_bf16");
+    return SVD_OK;
+}
+
+extern "C" int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, svd_bf16* Y, svd_stream_t stream) {
+    if (!t || !Y || n <= 0 || dim < 2) return SVD_EINVAL;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((int64_t)n * (dim / 2))), dim3(256), 0, (hipStream_t)stream, t, n,
+                       dim, logf(max_period), Y);
+    SVD_CHECK_LAUNCH("timestep_embedding");
+    return SVD_OK;
+}
+
+extern "C" int svd_edm_euler_step(float* x, const float* net, int64_t ldn, const float* guidance_scale, int32_t T, int32_t C,
+                                  int32_t pix, float sigma, float sigma_next, svd_stream_t stream) {
+    if (!x || !net || !guidance_scale || T <= 0 || C <= 0 || pix <= 0 || ldn < C || !(sigma > 0.f)) return SVD_EINVAL;
+    hipLaunchKernelGGL(edm_euler_step_kernel, dim3(grid_for((int64_t)T * pix)), dim3(256), 0, (hipStream_t)stream, x, net, ldn,
+                       guidance_scale, T, C, pix, sigma, sigma_next);
+    SVD_CHECK_LAUNCH("edm_euler_step");
+    return SVD_OK;
+}
+
+extern "C" int svd_ae_time_mix3(const float* X, int64_t ldx, const float* w, const float* b, float* Y, int32_t frames,
+                                int32_t pix, int32_t clamp, svd_stream_t stream) {
+    if (!X || !w || !b || !Y || frames <= 0 || pix <= 0 || ldx < 3) return SVD_EINVAL;
+    hipLaunchKernelGGL(ae_time_mix3_kernel, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0, (hipStream_t)stream, X, ldx, w, b,
+                       Y, frames, pix, clamp);
+    SVD_CHECK_LAUNCH("ae_time_mix3");
+    return SVD_OK;
+}

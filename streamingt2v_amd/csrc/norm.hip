@@ -1,0 +1,260 @@
+// GroupNorm(32) (+SiLU) and LayerNorm on channels-last bf16 activations -- HBM-bound kernels, fp32 statistics.
+#include "svd_common.h"
+
+namespace {
+
+constexpr int GN_MAXCHUNK = 256;
+
+__host__ __device__ inline int gn_nchunk(int frames, int pix) {
+    int n = (2048 + frames - 1) / frames;
+    const int maxc = (pix + 31) / 32;
+    if (n > maxc) n = maxc;
+    if (n > GN_MAXCHUNK) n = GN_MAXCHUNK;
+    if (n < 1) n = 1;
+    return n;
+}
+
+// blockDim = octets * R ; thread -> fixed channel octet (8 channels), rows strided by R.
+// partial[f][chunk][g][2] = (sum, sumsq) over the chunk's pixels of group g.
+__global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t ldx, int pix, int channels, int groups,
+                                        int nchunk, float* __restrict__ partial) {
+    extern __shared__ float sch[];   // [channels][2]
+    const int octets = channels >> 3;
+    const int R = blockDim.x / octets;
+    const int o = threadIdx.x % octets, rr = threadIdx.x / octets;
+    const int f = blockIdx.y, chunk = blockIdx.x;
+    const int rows_per_chunk = (pix + nchunk - 1) / nchunk;
+    const int r0 = chunk * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk; if (r1 > pix) r1 = pix;
+    for (int i = threadIdx.x; i < 2 * channels; i += blockDim.x) sch[i] = 0.f;
+    __syncthreads();
+    float s[8], ss[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+    if (rr < R) {
+        const svd_bf16* base = X + ((int64_t)f * pix) * ldx + o * 8;
+        for (int r = r0 + rr; r < r1; r += R) {
+            const uint4 u = *(const uint4*)(base + (int64_t)r * ldx);
+            float v[8] = {bf16lo_to_f32(u.x), bf16hi_to_f32(u.x), bf16lo_to_f32(u.y), bf16hi_to_f32(u.y),
+                          bf16lo_to_f32(u.z), bf16hi_to_f32(u.z), bf16lo_to_f32(u.w), bf16hi_to_f32(u.w)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += v[i]; ss[i] += v[i] * v[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(&sch[(o * 8 + i) * 2 + 0], s[i]);
+            atomicAdd(&sch[(o * 8 + i) * 2 + 1], ss[i]);
+        }
+    }
+    __syncthreads();
+    const int cpg = channels / groups;
+    if ((int)threadIdx.x < groups) {
+        float a = 0.f, b = 0.f;
+        for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { a += sch[2 * c]; b += sch[2 * c + 1]; }
+        float* p = partial + (((int64_t)f * nchunk + chunk) * groups + threadIdx.x) * 2;
+        p[0] = a; p[1] = b;
+    }
+}
+
+// one thread per (stat batch, group): reduce frames_per_stat * nchunk partials -> (mean, rstd)
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nstat, int groups, int frames_per_stat,
+                                   int nchunk, float count, float eps, float* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstat * groups) return;
+    const int sb = i / groups, g = i - sb * groups;
+    double a = 0.0, b = 0.0;
+    for (int fr = 0; fr < frames_per_stat; ++fr) {
+        const int f = sb * frames_per_stat + fr;
+        for (int c = 0; c < nchunk; ++c) {
+            const float* p = partial + (((int64_t)f * nchunk + c) * groups + g) * 2;
+            a += p[0]; b += p[1];
+        }
+    }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i + 0] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int pix,
+                                int channels, int groups, int frames_per_stat, int nchunk, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int silu) {
+    const int octets = channels >> 3;
+    const int R = blockDim.x / octets;
+    const int o = threadIdx.x % octets, rr = threadIdx.x / octets;
+    if (rr >= R) return;
+    const int f = blockIdx.y, chunk = blockIdx.x;
+    const int rows_per_chunk = (pix + nchunk - 1) / nchunk;
+    const int r0 = chunk * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk; if (r1 > pix) r1 = pix;
+    const int cpg = channels / groups;
+    const int sb = f / frames_per_stat;
+    float ca[8], cb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = o * 8 + i;
+        const int g = c / cpg;
+        const float mean = stats[((int64_t)sb * groups + g) * 2], rstd = stats[((int64_t)sb * groups + g) * 2 + 1];
+        const float ga = gamma[c] * rstd;
+        ca[i] = ga; cb[i] = beta[c] - mean * ga;
+    }
+    const svd_bf16* xb = X + ((int64_t)f * pix) * ldx + o * 8;
+    svd_bf16* yb = Y + ((int64_t)f * pix) * ldy + o * 8;
+    for (int r = r0 + rr; r < r1; r += R) {
+        const uint4 u = *(const uint4*)(xb + (int64_t)r * ldx);
+        float v[8] = {bf16lo_to_f32(u.x), bf16hi_to_f32(u.x), bf16lo_to_f32(u.y), bf16hi_to_f32(u.y),
+                      bf16lo_to_f32(u.z), bf16hi_to_f32(u.z), bf16lo_to_f32(u.w), bf16hi_to_f32(u.w)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = v[i] * ca[i] + cb[i];
+            if (silu) v[i] = silu_f(v[i]);
+        }
+        uint4 w;
+        w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
+        w.z = pack_bf16x2(v[4], v[5]); w.w = pack_bf16x2(v[6], v[7]);
+        *(uint4*)(yb + (int64_t)r * ldy) = w;
+    }
+}
+
+// LayerNorm: one wave per token row; up to MAXV 16-byte vectors per lane (C <= 64*8*MAXV).
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y,
+                                                        int64_t ldy, int64_t rows, int channels, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ addvec, int addvec_ld, int rows_per_vec,
+                                                        svd_bf16* __restrict__ Xsum, int64_t ldxsum, int silu) {
+    const int lane = threadIdx.x & 63;
+    const int octets = channels >> 3;
+    const float invc = 1.f / (float)channels;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        float v[MAXV][8];
+        float sum = 0.f;
+        const svd_bf16* xr = X + row * ldx;
+        const float* av = addvec ? addvec + (row / rows_per_vec) * addvec_ld : nullptr;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int o = lane + 64 * k;
+            if (o < octets) {
+                const uint4 u = *(const uint4*)(xr + o * 8);
+                v[k][0] = bf16lo_to_f32(u.x); v[k][1] = bf16hi_to_f32(u.x); v[k][2] = bf16lo_to_f32(u.y); v[k][3] = bf16hi_to_f32(u.y);
+                v[k][4] = bf16lo_to_f32(u.z); v[k][5] = bf16hi_to_f32(u.z); v[k][6] = bf16lo_to_f32(u.w); v[k][7] = bf16hi_to_f32(u.w);
+                if (av) {
+                    const float4 a0 = *(const float4*)(av + o * 8), a1 = *(const float4*)(av + o * 8 + 4);
+                    v[k][0] += a0.x; v[k][1] += a0.y; v[k][2] += a0.z; v[k][3] += a0.w;
+                    v[k][4] += a1.x; v[k][5] += a1.y; v[k][6] += a1.z; v[k][7] += a1.w;
+                    if (Xsum) {
+                        uint4 w;
+                        w.x = pack_bf16x2(v[k][0], v[k][1]); w.y = pack_bf16x2(v[k][2], v[k][3]);
+                        w.z = pack_bf16x2(v[k][4], v[k][5]); w.w = pack_bf16x2(v[k][6], v[k][7]);
+                        *(uint4*)(Xsum + row * ldxsum + o * 8) = w;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += v[k][i];
+            }
+        }
+        const float mean = wave_sum(sum) * invc;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int o = lane + 64 * k;
+            if (o < octets) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * invc + eps);
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int o = lane + 64 * k;
+            if (o < octets) {
+                const float4 g0 = *(const float4*)(gamma + o * 8), g1 = *(const float4*)(gamma + o * 8 + 4);
+                const float4 b0 = *(const float4*)(beta + o * 8), b1 = *(const float4*)(beta + o * 8 + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    y[i] = (v[k][i] - mean) * rstd * gg[i] + bb[i];
+                    if (silu) y[i] = silu_f(y[i]);
+                }
+                uint4 w;
+                w.x = pack_bf16x2(y[0], y[1]); w.y = pack_bf16x2(y[2], y[3]);
+                w.z = pack_bf16x2(y[4], y[5]); w.w = pack_bf16x2(y[6], y[7]);
+                *(uint4*)(Y + row * ldy + o * 8) = w;
+            }
+        }
+    }
+}
+
+inline int gn_block(int channels) {
+    const int octets = channels >> 3;
+    int R = 256 / octets; if (R < 1) R = 1;
+    return octets * R;
+}
+
+}  // namespace
+
+extern "C" int64_t svd_groupnorm_partial_elems(int32_t frames, int32_t channels) {
+    (void)channels;
+    return (int64_t)frames * GN_MAXCHUNK * 64;
+}
+
+extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
+                                   int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats,
+                                   svd_stream_t stream) {
+    if (!X || !partial || !stats || frames <= 0 || pix <= 0 || channels <= 0) return SVD_EINVAL;
+    if (groups <= 0 || groups > 32 || channels % groups || channels % 8 || ldx % 8 || channels > 8192) return SVD_EINVAL;
+    if (frames_per_stat <= 0 || frames % frames_per_stat || frames > 65535) return SVD_EINVAL;
+    if ((uintptr_t)X & 15) return SVD_EINVAL;
+    const int nchunk = gn_nchunk(frames, pix);
+    const int bs = gn_block(channels);
+    hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, frames), dim3(bs), 2 * channels * sizeof(float),
+                       (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial);
+    SVD_CHECK_LAUNCH("gn_stats_partial");
+    const int nstat = frames / frames_per_stat;
+    const float count = (float)frames_per_stat * (float)pix * (float)(channels / groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial,
+                       nstat, groups, frames_per_stat, nchunk, count, eps, stats);
+    SVD_CHECK_LAUNCH("gn_finalize");
+    return SVD_OK;
+}
+
+extern "C" int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
+                                   int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
+                                   const float* gamma, const float* beta, int32_t silu, svd_stream_t stream) {
+    if (!X || !Y || !stats || !gamma || !beta || frames <= 0 || pix <= 0) return SVD_EINVAL;
+    if (groups <= 0 || groups > 32 || channels % groups || channels % 8 || ldx % 8 || ldy % 8 || channels > 8192) return SVD_EINVAL;
+    if (frames_per_stat <= 0 || frames % frames_per_stat || frames > 65535) return SVD_EINVAL;
+    if (((uintptr_t)X | (uintptr_t)Y) & 15) return SVD_EINVAL;
+    const int nchunk = gn_nchunk(frames, pix);
+    const int bs = gn_block(channels);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy, pix,
+                       channels, groups, frames_per_stat, nchunk, stats, gamma, beta, silu);
+    SVD_CHECK_LAUNCH("gn_apply");
+    return SVD_OK;
+}
+
+extern "C" int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
+                             const float* gamma, const float* beta, float eps, const float* addvec, int32_t addvec_ld,
+                             int32_t rows_per_vec, svd_bf16* Xsum, int64_t ldxsum, int32_t silu, svd_stream_t stream) {
+    if (!X || !Y || !gamma || !beta || rows <= 0 || channels <= 0 || channels % 8 || ldx % 8 || ldy % 8) return SVD_EINVAL;
+    if (channels > 64 * 8 * 4) return SVD_EINVAL;
+    if (addvec && (rows_per_vec <= 0 || addvec_ld % 4)) return SVD_EINVAL;
+    if (Xsum && (!addvec || ldxsum % 8)) return SVD_EINVAL;
+    if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)addvec | (uintptr_t)Xsum) & 15) return SVD_EINVAL;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const int octets = channels / 8;
+#define LN_LAUNCH(MV)                                                                                              \
+    hipLaunchKernelGGL(layernorm_kernel<MV>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, \
+                       rows, channels, gamma, beta, eps, addvec, addvec_ld, rows_per_vec, Xsum, ldxsum, silu)
+    if (octets <= 64) LN_LAUNCH(1);
+    else if (octets <= 128) LN_LAUNCH(2);
+    else if (octets <= 192) LN_LAUNCH(3);
+    else LN_LAUNCH(4);
+#undef LN_LAUNCH
+    SVD_CHECK_LAUNCH("layernorm");
+    return SVD_OK;
+}

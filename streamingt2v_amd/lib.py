@@ -1,0 +1,105 @@
+"""ctypes binding of libsvdhip.so (the C ABI declared in include/svdhip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` / ``make -C streamingt2v_amd/csrc``.
+There is NO fallback: if the library is missing or a symbol is absent the import fails loudly -- the product
+path never silently degrades to PyTorch ops or to the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvdhip.so")
+
+ABI_VERSION = 1
+
+# entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
+SYMBOLS = [
+    "svd_abi_version", "svd_last_error", "svd_gemm", "svd_gemm_num_configs", "svd_gemm_config_info",
+    "svd_attn_spatial_d64", "svd_attn_temporal_d64", "svd_softmax_rows",
+    "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_layernorm",
+    "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_silu_f32_to_bf16",
+    "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
+]
+
+A_PLAIN, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
+OUT_BF16, OUT_F32, OUT_BF16_T = 0, 1, 2
+EPI_GEGLU = 1
+EPI_SILU = 2
+
+
+class GemmArgs(C.Structure):
+    """Mirror of ``struct svd_gemm_args`` (field order and types must match include/svdhip.h)."""
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_mode", C.c_int32),
+        ("cin", C.c_int32),
+        ("hin", C.c_int32), ("win", C.c_int32),
+        ("hout", C.c_int32), ("wout", C.c_int32),
+        ("stride", C.c_int32), ("ups", C.c_int32),
+        ("t_frames", C.c_int32), ("rows_per_frame", C.c_int32),
+        ("zeros", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_vec", C.c_int32),
+        ("R", C.c_void_p), ("ldr", C.c_int64),
+        ("S", C.c_void_p), ("lds", C.c_int64),
+        ("alpha", C.c_float),
+        ("epi_flags", C.c_int32),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("out_mode", C.c_int32),
+        ("tok_per_frame", C.c_int32), ("tokens_ld", C.c_int64),
+        ("tile_cfg", C.c_int32),
+    ]
+
+
+class SvdHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or make -C streamingt2v_amd/csrc). There is no non-HIP fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"libsvdhip.so lacks symbols declared in include/svdhip.h: {missing}")
+    lib.svd_abi_version.restype = C.c_int
+    lib.svd_last_error.restype = C.c_char_p
+    lib.svd_groupnorm_partial_elems.restype = C.c_int64
+    lib.svd_groupnorm_partial_elems.argtypes = [C.c_int32, C.c_int32]
+    i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+    lib.svd_gemm.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.svd_gemm_config_info.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 4
+    lib.svd_attn_spatial_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
+    lib.svd_attn_temporal_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]
+    lib.svd_softmax_rows.argtypes = [vp, i64, vp, i64, i64, i32, f32, vp]
+    lib.svd_groupnorm_stats.argtypes = [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp]
+    lib.svd_groupnorm_apply.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+    lib.svd_layernorm.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, f32, vp, i32, i32, vp, i64, i32, vp]
+    lib.svd_nchw_to_tokens.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]
+    lib.svd_tokens_to_nchw.argtypes = [vp, i32, i64, vp, i32, i32, i32, vp]
+    lib.svd_concat_channels.argtypes = [vp, i64, i32, vp, i64, i32, vp, i64, i64, vp]
+    lib.svd_add_rows.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
+    lib.svd_silu_f32_to_bf16.argtypes = [vp, vp, i64, i32, vp]
+    lib.svd_timestep_embedding.argtypes = [vp, i32, i32, f32, vp, vp]
+    lib.svd_edm_euler_step.argtypes = [vp, vp, i64, vp, i32, i32, i32, f32, f32, vp]
+    lib.svd_ae_time_mix3.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, vp]
+    for s in SYMBOLS:
+        fn = getattr(lib, s)
+        if s not in ("svd_last_error", "svd_groupnorm_partial_elems"):
+            fn.restype = C.c_int
+    if lib.svd_abi_version() != ABI_VERSION:
+        raise ImportError(f"libsvdhip.so ABI {lib.svd_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib.svd_last_error().decode() if rc == -2 else "invalid argument (SVD_EINVAL)"
+        raise SvdHipError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,233 @@
+"""Tensor-level launchers for the libsvdhip.so kernels.
+
+PyTorch is plumbing only here: it owns device memory and the stream.  Every function below passes raw
+pointers + sizes + the current HIP stream through the C ABI (include/svdhip.h); no arithmetic happens in torch.
+Activations are "token" tensors: shape [rows, C] (rows = frames * pixels), bf16, channels contiguous.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _l
+from .lib import A_CONV3X3, A_PLAIN, A_TEMPORAL3, EPI_GEGLU, EPI_SILU, OUT_BF16, OUT_BF16_T, OUT_F32, GemmArgs, check
+
+_lib = _l.lib
+BF16 = torch.bfloat16
+
+_zeros = {}
+_gn_ws = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def zeros_page(device):
+    z = _zeros.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=BF16, device=device)
+        _zeros[device] = z
+    return z
+
+
+def _rows_ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "token tensor must be [rows, C] with contiguous channels"
+    return t.shape[0], t.stride(0)
+
+
+def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=None, geglu=False, silu=False,
+         out=None, out_f32=False, conv=None, temporal=None, trans_out=None, n_out=None, tile_cfg=0, k=None):
+    """C = epilogue(A_view . W^T).  See svd_gemm in include/svdhip.h.
+
+    a: [rows_src, lda] bf16 token tensor (for conv/temporal views: the SOURCE tensor).
+    w: [N, K] bf16.   conv = dict(cin, hin, win, hout, wout, stride, ups, frames)   temporal = dict(cin, T, pix, M)
+    blend = (alpha: float, S tensor).   trans_out = dict(tok_per_frame, tokens_ld, out=tensor [frames, N, tokens_ld])
+    """
+    assert a.dtype == BF16 and w.dtype == BF16 and a.is_cuda and w.is_cuda
+    N, K = w.shape[0], (k if k is not None else w.shape[1])
+    args = GemmArgs()
+    args.A, args.lda = a.data_ptr(), a.stride(0)
+    args.W, args.ldw = w.data_ptr(), w.stride(0)
+    args.zeros = zeros_page(a.device).data_ptr()
+    if conv is not None:
+        M = conv["frames"] * conv["hout"] * conv["wout"]
+        args.a_mode = A_CONV3X3
+        args.cin, args.hin, args.win = conv["cin"], conv["hin"], conv["win"]
+        args.hout, args.wout = conv["hout"], conv["wout"]
+        args.stride, args.ups = conv.get("stride", 1), conv.get("ups", 0)
+        assert a.shape[0] == conv["frames"] * conv["hin"] * conv["win"]
+    elif temporal is not None:
+        M = a.shape[0]
+        args.a_mode = A_TEMPORAL3
+        args.cin, args.t_frames, args.rows_per_frame = temporal["cin"], temporal["T"], temporal["pix"]
+    else:
+        M = a.shape[0]
+        args.a_mode = A_PLAIN
+    args.M, args.N, args.K = M, N, K
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N
+        args.bias = bias.data_ptr()
+    if rowvec is not None:
+        assert rowvec.dtype == torch.float32 and rowvec.stride(-1) == 1
+        args.rowvec, args.rowvec_ld, args.rows_per_vec = rowvec.data_ptr(), rowvec.stride(0), rows_per_vec
+    if residual is not None:
+        assert residual.dtype == BF16
+        args.R, args.ldr = residual.data_ptr(), residual.stride(0)
+    if blend is not None:
+        alpha, S = blend
+        assert S.dtype == BF16
+        args.S, args.lds, args.alpha = S.data_ptr(), S.stride(0), float(alpha)
+    nout = N // 2 if geglu else N
+    if n_out is not None:
+        nout = n_out
+    if geglu:
+        args.epi_flags = EPI_GEGLU
+    if silu:
+        args.epi_flags |= EPI_SILU
+    if trans_out is not None:
+        o = trans_out["out"]
+        assert o.dtype == BF16
+        args.C, args.ldc = o.data_ptr(), 0
+        args.out_mode = OUT_BF16_T
+        args.tok_per_frame, args.tokens_ld = trans_out["tok_per_frame"], trans_out["tokens_ld"]
+        out = o
+    else:
+        if out is None:
+            out = torch.empty((M, nout), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+        assert out.shape[0] == M and out.stride(1) == 1
+        args.C, args.ldc = out.data_ptr(), out.stride(0)
+        args.out_mode = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    args.tile_cfg = tile_cfg
+    check(_lib.svd_gemm(C.byref(args), _stream()), f"svd_gemm(M={M},N={N},K={K},mode={args.a_mode})")
+    return out
+
+
+def attn_spatial(q, k, vt, out, frames, n_tok, heads):
+    """q,k: views into a [frames*n_tok, ld] tensor at the head-0 column; vt: [frames, heads*64, tok_ld]."""
+    check(_lib.svd_attn_spatial_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out),
+                                    out.stride(0), frames, n_tok, heads, _stream()), "svd_attn_spatial_d64")
+    return out
+
+
+def attn_temporal(q, k, v, out, batch, tq, tk, n_pix, heads):
+    check(_lib.svd_attn_temporal_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
+                                     out.stride(0), batch, tq, tk, n_pix, heads, _stream()), "svd_attn_temporal_d64")
+    return out
+
+
+def softmax_rows(s, out, scale):
+    rows, n = s.shape
+    check(_lib.svd_softmax_rows(_p(s), s.stride(0), _p(out), out.stride(0), rows, n, float(scale), _stream()),
+          "svd_softmax_rows")
+    return out
+
+
+def _gn_workspace(device, frames, channels):
+    need = int(_lib.svd_groupnorm_partial_elems(frames, channels))
+    key = device
+    ws = _gn_ws.get(key)
+    if ws is None or ws[0].numel() < need:
+        ws = (torch.empty(max(need, 1 << 20), dtype=torch.float32, device=device),
+              torch.empty(65536, dtype=torch.float32, device=device))
+        _gn_ws[key] = ws
+    return ws
+
+
+def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False, groups=32, out=None):
+    """GroupNorm(32) (+SiLU) on a [frames*pix, C] token tensor; statistics over frames_per_stat frames."""
+    rows, ld = _rows_ld(x)
+    Cc = x.shape[1]
+    assert rows == frames * pix
+    partial, stats = _gn_workspace(x.device, frames, Cc)
+    check(_lib.svd_groupnorm_stats(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, float(eps), _p(partial),
+                                   _p(stats), _stream()), "svd_groupnorm_stats")
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+    check(_lib.svd_groupnorm_apply(_p(x), ld, _p(out), out.stride(0), frames, pix, Cc, groups, frames_per_stat,
+                                   _p(stats), _p(gamma), _p(beta), int(silu), _stream()), "svd_groupnorm_apply")
+    return out
+
+
+def layernorm(x, gamma, beta, *, eps=1e-5, addvec=None, rows_per_vec=0, want_sum=False, silu=False, out=None):
+    rows, ld = _rows_ld(x)
+    Cc = x.shape[1]
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+    xsum = torch.empty((rows, Cc), dtype=BF16, device=x.device) if want_sum else None
+    check(_lib.svd_layernorm(_p(x), ld, _p(out), out.stride(0), rows, Cc, _p(gamma), _p(beta), float(eps),
+                             _p(addvec), addvec.stride(0) if addvec is not None else 0, rows_per_vec,
+                             _p(xsum), xsum.stride(0) if xsum is not None else 0, int(silu), _stream()),
+          "svd_layernorm")
+    return (out, xsum) if want_sum else out
+
+
+def nchw_to_tokens(x0, x1, scale, cpad):
+    """[F,c0,H,W] (+ [F,c1,H,W]) fp32 -> [F*H*W, cpad] bf16 (x0 scaled per frame by scale[F])."""
+    F_, c0 = x0.shape[0], x0.shape[1]
+    pix = x0.shape[2] * x0.shape[3]
+    c1 = x1.shape[1] if x1 is not None else 0
+    assert x0.dtype == torch.float32 and x0.is_contiguous()
+    if x1 is not None:
+        assert x1.dtype == torch.float32 and x1.is_contiguous() and x1.shape[0] == F_
+    out = torch.empty((F_ * pix, cpad), dtype=BF16, device=x0.device)
+    check(_lib.svd_nchw_to_tokens(_p(x0), c0, _p(x1), c1, _p(scale), _p(out), cpad, F_, pix, _stream()),
+          "svd_nchw_to_tokens")
+    return out
+
+
+def tokens_to_nchw(x, c, frames, h, w):
+    out = torch.empty((frames, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.svd_tokens_to_nchw(_p(x), int(x.dtype == torch.float32), x.stride(0), _p(out), c, frames, h * w,
+                                  _stream()), "svd_tokens_to_nchw")
+    return out
+
+
+def concat_channels(a, b):
+    rows = a.shape[0]
+    out = torch.empty((rows, a.shape[1] + b.shape[1]), dtype=BF16, device=a.device)
+    check(_lib.svd_concat_channels(_p(a), a.stride(0), a.shape[1], _p(b), b.stride(0), b.shape[1], _p(out),
+                                   out.stride(0), rows, _stream()), "svd_concat_channels")
+    return out
+
+
+def add_rows(x, b):
+    out = torch.empty_like(x)
+    check(_lib.svd_add_rows(_p(x), x.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1],
+                            _stream()), "svd_add_rows")
+    return out
+
+
+def to_bf16(x, silu=False):
+    """fp32 -> bf16 (optionally through SiLU) -- the only 'cast' kernel; x any shape, contiguous."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(_lib.svd_silu_f32_to_bf16(_p(x), _p(out), x.numel(), int(silu), _stream()), "svd_silu_f32_to_bf16")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    out = torch.empty((t.numel(), dim), dtype=BF16, device=t.device)
+    check(_lib.svd_timestep_embedding(_p(t), t.numel(), dim, float(max_period), _p(out), _stream()),
+          "svd_timestep_embedding")
+    return out
+
+
+def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
+    """In-place Euler-EDM step on x [T,C,H,W] fp32 given the raw network output net [2T*pix, ldn] fp32."""
+    T, Cc = x.shape[0], x.shape[1]
+    pix = x.shape[2] * x.shape[3]
+    check(_lib.svd_edm_euler_step(_p(x), _p(net), net.stride(0), _p(guidance_scale), T, Cc, pix, float(sigma),
+                                  float(sigma_next), _stream()), "svd_edm_euler_step")
+    return x
+
+
+def ae_time_mix3(x, w, b, frames, h, wd, clamp):
+    out = torch.empty((frames, 3, h, wd), dtype=torch.float32, device=x.device)
+    check(_lib.svd_ae_time_mix3(_p(x), x.stride(0), _p(w), _p(b), _p(out), frames, h * wd, int(clamp), _stream()),
+          "svd_ae_time_mix3")
+    return out

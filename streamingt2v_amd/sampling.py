@@ -1,0 +1,94 @@
+"""Euler-EDM sampling stack of StreamingSVD (host loop in Python, arithmetic in libsvdhip.so kernels).
+
+Mirrors:
+  AlignYourSteps                      <- code/models/diffusion/discretizer.py:8-33 (+ append_zero, sgm discretizer.py:18-22)
+  VScalingWithEDMcNoise               <- code/models/svd/sgm/modules/diffusionmodules/denoiser_scaling.py:51-59
+  Denoiser                            <- .../denoiser.py:11-39
+  LinearPredictionGuider              <- .../guiders.py:60-99
+  EulerEDMSampler (s_churn = 0)       <- .../sampling.py:41-52, 93-130, 211-215
+
+The sigma schedule is float64 on the host exactly as in the reference; per-step sigmas reach the kernels as fp32.
+Two ways to run a step:
+  * reference-shaped: ``Denoiser``/``LinearPredictionGuider`` objects + any ``network(x, c_noise, cond, **kw)``
+    callable (used by the drop-in tests);
+  * fused (``EulerEDMSampler.__call__`` with a StreamingWrapper): the c_in scaling rides in the NCHW->token
+    conversion kernel and denoiser-combine + guidance + Euler update are one kernel on the fp32 state.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class AlignYourSteps:
+    """Log-linear interpolation of the 11-point AYS schedule (sigma_max 700)."""
+
+    SCHEDULE = [700.00, 54.5, 15.886, 7.977, 4.248, 1.789, 0.981, 0.403, 0.173, 0.034, 0.002]
+
+    def __init__(self, sigma_min=0.002, sigma_max=700.0, rho=7.0):
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def get_sigmas(self, n):
+        t = np.array(self.SCHEDULE)
+        xs = np.linspace(0, 1, len(t))
+        ys = np.log(t[::-1])
+        new_ys = np.interp(np.linspace(0, 1, n), xs, ys)
+        return np.exp(new_ys)[::-1].copy()
+
+    def __call__(self, n, do_append_zero=True):
+        s = self.get_sigmas(n)
+        return np.concatenate([s, [0.0]]) if do_append_zero else s
+
+
+class VScalingWithEDMcNoise:
+    def __call__(self, sigma):
+        s2 = sigma * sigma + 1.0
+        return 1.0 / s2, -sigma / math.sqrt(s2), 1.0 / math.sqrt(s2), 0.25 * math.log(sigma)
+
+
+class LinearPredictionGuider:
+    def __init__(self, max_scale=3.0, num_frames=25, min_scale=1.5):
+        self.min_scale, self.max_scale, self.num_frames = min_scale, max_scale, num_frames
+        self.scale = torch.linspace(min_scale, max_scale, num_frames)
+
+    def prepare_inputs(self, x, s, c, uc):
+        c_out = {k: torch.cat((uc[k], c[k]), 0) for k in ("vector", "crossattn", "concat")}
+        return torch.cat([x] * 2), torch.cat([s] * 2), c_out
+
+
+class EulerEDMSampler:
+    """30 Euler steps on the AYS schedule with per-frame linear guidance (config.yaml:139-158)."""
+
+    def __init__(self, num_steps=30, num_frames=25, min_scale=1.5, max_scale=3.0, discretization=None):
+        self.num_steps = num_steps
+        self.discretization = discretization or AlignYourSteps()
+        self.guider = LinearPredictionGuider(max_scale=max_scale, num_frames=num_frames, min_scale=min_scale)
+        self.scaling = VScalingWithEDMcNoise()
+        self._gscale = {}
+
+    def sigmas(self, num_steps=None):
+        return self.discretization(self.num_steps if num_steps is None else num_steps)
+
+    def __call__(self, wrapper, x, cond, uc, num_steps=None, **model_kwargs):
+        """x: [T, 4, h, w] fp32 noise (modified in place, like the reference's ``x *= sqrt(1 + sigma0^2)``);
+        cond/uc: dicts with 'concat' [T,4,h,w], 'crossattn' [T,1,1024], 'vector' [T,768];
+        wrapper: streamingt2v_amd.wrappers.StreamingWrapper.  Returns the denoised latents [T,4,h,w] fp32."""
+        sig = self.sigmas(num_steps)                         # float64
+        T = x.shape[0]
+        assert T == self.guider.num_frames
+        x.mul_(float(np.sqrt(1.0 + sig[0] ** 2.0)))           # prepare_sampling_loop (sampling.py:47)
+        dev = x.device
+        g = self._gscale.get(dev)
+        if g is None:
+            g = self.guider.scale.to(dev).float().contiguous()
+            self._gscale[dev] = g
+        c2 = {k: torch.cat((uc[k], cond[k]), 0).float().contiguous() for k in ("vector", "crossattn", "concat")}
+        for i in range(len(sig) - 1):
+            s = float(np.float32(sig[i]))                     # s_in * sigmas[i] is fp32 in the reference
+            s_next = float(np.float32(sig[i + 1]))
+            _, _, c_in, c_noise = self.scaling(s)
+            net = wrapper.forward_fused(x, c_in, c_noise, c2, **model_kwargs)   # [2T*pix, 4] fp32 tokens
+            ops.edm_euler_step(x, net, g, s, s_next)
+        return x

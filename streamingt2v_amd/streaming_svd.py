@@ -1,0 +1,69 @@
+"""StreamingSVD generation driver: one conditional chunk and the autoregressive outer loop.
+
+Mirrors code/diffusion_trainer/streaming_svd.py:
+  decode_first_stage              :123-151   (z / 0.18215, groups of 8 frames, fp32 output)
+  _generate_conditional_output    :155-221   (noise -> EulerEDMSampler -> decode -> clamp)
+  _autoregressive_generation      :293-356   (ctrl_frames = last 7 decoded frames, anchor = chunk0[6], keep result[7:])
+
+Out of scope here: the conditioner (OpenCLIP ViT-H image tower + VAE encoder) that turns the anchor
+frame into ``c``/``uc``.  It runs once per chunk; callers pass a ``conditioner(svd_input_frame) -> (c, uc)``
+callable (the reference's GeneralConditioner, or synthetic tensors of the right shapes in bench/tests).
+Noise is injected explicitly (``noise=``) because the reference draws from the global torch RNG
+(streaming_svd.py:203), which is not reproducible across devices.
+"""
+import math
+
+import torch
+
+from .sampling import EulerEDMSampler
+
+
+class StreamingSVD:
+    def __init__(self, inference_model, first_stage_model, sampler=None, scale_factor=0.18215,
+                 num_conditional_frames=7, use_memopt=False):
+        self.inference_model = inference_model          # StreamingWrapper
+        self.first_stage_model = first_stage_model      # object with .decode(z, timesteps=n) and .decoder
+        self.sampler = sampler or EulerEDMSampler()
+        self.scale_factor = scale_factor
+        self.num_conditional_frames = num_conditional_frames
+        self.use_memopt = use_memopt
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, clamp=False):
+        z = z * (1.0 / self.scale_factor)
+        n_samples = min(z.shape[0], 4 if self.use_memopt else 8)
+        outs = []
+        for n in range(math.ceil(z.shape[0] / n_samples)):
+            zc = z[n * n_samples:(n + 1) * n_samples]
+            outs.append(self.first_stage_model.decode(zc, timesteps=len(zc), clamp=clamp))
+        return torch.cat(outs, dim=0)
+
+    @torch.no_grad()
+    def _generate_conditional_output(self, c, uc, ctrl_frames, noise, num_steps=None):
+        """c/uc: per-frame-repeated conditioning dicts ('crossattn' [T,1,1024], 'concat' [T,4,h,w], 'vector' [T,768]);
+        ctrl_frames [1, Tc, 3, H, W] in [-1,1]; noise [T,4,h,w].  Returns frames [T,3,H,W] fp32 clamped to [-1,1]."""
+        T = self.sampler.guider.num_frames
+        assert noise.shape[0] == T
+        x = noise.clone().float().contiguous()
+        samples_z = self.sampler(self.inference_model, x, c, uc, num_steps=num_steps, batch_size=2,
+                                 num_video_frames=T, ctrl_frames=ctrl_frames)
+        return self.decode_first_stage(samples_z, clamp=True)          # torch.clamp(-1, 1) fused (streaming_svd.py:220)
+
+    @staticmethod
+    def extract_ctrl_frames(video, num_conditional_frames):
+        """Last frames of the previous chunk as [1, Tc, 3, H, W] (streaming_svd.py:263-290)."""
+        return video[-num_conditional_frames:][None].contiguous()
+
+    @torch.no_grad()
+    def _autoregressive_generation(self, initial_generation, conditioner, n_autoregressive_generations, noises,
+                                   anchor_index=6, num_steps=None):
+        """initial_generation [T0,3,H,W] in [-1,1] (chunk 0); returns all frames [T0 + n*(T-Tc), 3, H, W]."""
+        Tc = self.num_conditional_frames
+        result_chunks = [initial_generation]
+        anchor = initial_generation[anchor_index]                         # streaming_svd.py:336
+        for k in range(n_autoregressive_generations):
+            ctrl_frames = self.extract_ctrl_frames(result_chunks[-1], Tc)
+            c, uc = conditioner(anchor)
+            result = self._generate_conditional_output(c, uc, ctrl_frames, noises[k], num_steps=num_steps)
+            result_chunks.append(result[Tc:])                             # the overlap frames are re-generated, dropped
+        return torch.cat(result_chunks, dim=0)

@@ -1,0 +1,213 @@
+"""Temporal VAE decoder (SVD's VideoDecoder, time_mode "conv-only") on the libsvdhip.so kernels.
+
+Mirrors code/models/svd/sgm/modules/autoencoding/temporal_ae.py:16-105,291-347 and
+code/models/svd/sgm/modules/diffusionmodules/model.py:94-201,603-748 (Decoder, ResnetBlock, AttnBlock, Upsample),
+state_dict keys as under ``first_stage_model.decoder.`` of the reference checkpoint.
+
+Same execution plan as the UNet: channels-last bf16 tokens, 3x3 convs and (3,1,1) temporal convs as implicit
+GEMMs (nearest-2x upsample folded into the conv addressing), GroupNorm+SiLU kernels, bias/residual/alpha-blend
+epilogues.  The single-head (d = 512) mid attention is QK^T GEMM (fp32 scores) -> row softmax -> PV GEMM per
+frame.  The reference runs this decoder in fp32 (config.yaml:310); bf16 storage / fp32 accumulation here, the
+parity tolerance is stated in tests/test_gpu_parity.py.
+"""
+import torch
+
+from . import ops
+from .params import Spec, check_state_dict
+from .video_model import BF16, _Conv, _dev_bf16, _dev_f32, _sigmoid, pack_conv3x3, pack_tconv3, pad_rows
+
+
+class VaeConfig:
+    """decoder_config of config.yaml:241-258."""
+
+    def __init__(self, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, out_ch=3):
+        self.ch, self.ch_mult, self.num_res_blocks = ch, tuple(ch_mult), num_res_blocks
+        self.z_channels, self.out_ch = z_channels, out_ch
+
+
+class AEVideoResBlock:
+    """ResnetBlock (temb=None) -> time_stack ResBlock(3,1,1; no emb) -> alpha*temporal + (1-alpha)*spatial."""
+
+    def __init__(self, prefix, cin, cout):
+        self.p, self.cin, self.cout = prefix, cin, cout
+
+    def spec(self, s):
+        p, ci, co = self.p, self.cin, self.cout
+        s.add(p + "norm1.weight", ci); s.add(p + "norm1.bias", ci)
+        s.add(p + "conv1.weight", co, ci, 3, 3); s.add(p + "conv1.bias", co)
+        s.add(p + "norm2.weight", co); s.add(p + "norm2.bias", co)
+        s.add(p + "conv2.weight", co, co, 3, 3); s.add(p + "conv2.bias", co)
+        if ci != co:
+            s.add(p + "nin_shortcut.weight", co, ci, 1, 1); s.add(p + "nin_shortcut.bias", co)
+        t = p + "time_stack."
+        s.add(t + "in_layers.0.weight", co); s.add(t + "in_layers.0.bias", co)
+        s.add(t + "in_layers.2.weight", co, co, 3, 1, 1); s.add(t + "in_layers.2.bias", co)
+        s.add(t + "out_layers.0.weight", co); s.add(t + "out_layers.0.bias", co)
+        s.add(t + "out_layers.3.weight", co, co, 3, 1, 1); s.add(t + "out_layers.3.bias", co)
+        s.add(p + "mix_factor", 1)
+
+    def prepare(self, sd, dev):
+        g = lambda k: sd[self.p + k]
+        Fv = lambda k: _dev_f32(g(k), dev)
+        self.n1, self.n2 = (Fv("norm1.weight"), Fv("norm1.bias")), (Fv("norm2.weight"), Fv("norm2.bias"))
+        self.w1, self.b1 = _dev_bf16(pack_conv3x3(g("conv1.weight")), dev), Fv("conv1.bias")
+        self.w2, self.b2 = _dev_bf16(pack_conv3x3(g("conv2.weight")), dev), Fv("conv2.bias")
+        if self.cin != self.cout:
+            self.ws, self.bs = _dev_bf16(g("nin_shortcut.weight")[:, :, 0, 0], dev), Fv("nin_shortcut.bias")
+        t = "time_stack."
+        self.tn1, self.tn2 = (Fv(t + "in_layers.0.weight"), Fv(t + "in_layers.0.bias")), (Fv(t + "out_layers.0.weight"), Fv(t + "out_layers.0.bias"))
+        self.tw1, self.tb1 = _dev_bf16(pack_tconv3(g(t + "in_layers.2.weight")), dev), Fv(t + "in_layers.2.bias")
+        self.tw2, self.tb2 = _dev_bf16(pack_tconv3(g(t + "out_layers.3.weight")), dev), Fv(t + "out_layers.3.bias")
+        self.alpha = _sigmoid(g("mix_factor"))
+
+    def forward(self, x, F, H, W):
+        pix = H * W
+        cvi = dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F)
+        cv = dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F)
+        tv = dict(cin=self.cout, T=F, pix=pix)
+        h = ops.groupnorm(x, F, pix, *self.n1, 1e-6, silu=True)
+        h = ops.gemm(h, self.w1, bias=self.b1, conv=cvi)
+        h = ops.groupnorm(h, F, pix, *self.n2, 1e-6, silu=True)
+        skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
+        hs = ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=cv)
+        g = ops.groupnorm(hs, F, pix, *self.tn1, 1e-5, frames_per_stat=F, silu=True)
+        g = ops.gemm(g, self.tw1, bias=self.tb1, temporal=tv)
+        g = ops.groupnorm(g, F, pix, *self.tn2, 1e-5, frames_per_stat=F, silu=True)
+        # x = alpha * temporal + (1 - alpha) * spatial   (temporal_ae.py:77-78: opposite convention to the UNet)
+        return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(1.0 - self.alpha, hs), temporal=tv)
+
+
+class AEAttnBlock:
+    """AttnBlock (model.py:161-201): one head of width C over H*W tokens per frame."""
+
+    def __init__(self, prefix, ch):
+        self.p, self.c = prefix, ch
+        self._vt = {}
+
+    def spec(self, s):
+        p, c = self.p, self.c
+        s.add(p + "norm.weight", c); s.add(p + "norm.bias", c)
+        for n in ("q", "k", "v", "proj_out"):
+            s.add(p + n + ".weight", c, c, 1, 1); s.add(p + n + ".bias", c)
+
+    def prepare(self, sd, dev):
+        g = lambda k: sd[self.p + k]
+        self.dev = dev
+        self.n = (_dev_f32(g("norm.weight"), dev), _dev_f32(g("norm.bias"), dev))
+        self.wqk = _dev_bf16(torch.cat([g("q.weight")[:, :, 0, 0], g("k.weight")[:, :, 0, 0]], 0), dev)
+        self.bqk = _dev_f32(torch.cat([g("q.bias"), g("k.bias")], 0), dev)
+        self.wv, self.bv = _dev_bf16(g("v.weight")[:, :, 0, 0], dev), _dev_f32(g("v.bias"), dev)
+        self.wo, self.bo = _dev_bf16(g("proj_out.weight")[:, :, 0, 0], dev), _dev_f32(g("proj_out.bias"), dev)
+
+    def forward(self, x, F, H, W):
+        c, pix = self.c, H * W
+        assert pix % 64 == 0, "VAE mid attention expects H*W to be a multiple of 64"
+        h = ops.groupnorm(x, F, pix, *self.n, 1e-6, silu=False)
+        qk = ops.gemm(h, self.wqk, bias=self.bqk)                       # [F*pix, 2C]
+        key = (F, pix)
+        vt = self._vt.get(key)
+        if vt is None:
+            vt = torch.zeros((F, c, pix), dtype=BF16, device=self.dev)
+            self._vt[key] = vt
+        ops.gemm(h, self.wv, bias=self.bv, trans_out=dict(tok_per_frame=pix, tokens_ld=pix, out=vt))
+        o = torch.empty((F * pix, c), dtype=BF16, device=x.device)
+        s = torch.empty((pix, pix), dtype=torch.float32, device=x.device)
+        p = torch.empty((pix, pix), dtype=BF16, device=x.device)
+        for f in range(F):
+            q_f, k_f = qk[f * pix:(f + 1) * pix, :c], qk[f * pix:(f + 1) * pix, c:]
+            ops.gemm(q_f, k_f, out=s)                                    # scores = q k^T  (fp32)
+            ops.softmax_rows(s, p, c ** -0.5)
+            ops.gemm(p, vt[f], out=o[f * pix:(f + 1) * pix])             # o = P V  (W operand = V^T)
+        return ops.gemm(o, self.wo, bias=self.bo, residual=x)
+
+
+class VideoDecoder:
+    """temporal_ae.py:291-347 / model.py:603-748.  ``forward(z, timesteps=n)`` keeps the reference contract:
+    z [n, 4, h, w] fp32 (already divided by the scale factor) -> [n, 3, 8h, 8w] fp32."""
+
+    def __init__(self, cfg=None):
+        cfg = cfg or VaeConfig()
+        self.cfg = cfg
+        nres = len(cfg.ch_mult)
+        block_in = cfg.ch * cfg.ch_mult[-1]
+        self.conv_in = _Conv("conv_in.", cfg.z_channels, block_in)
+        self.mid_block_1 = AEVideoResBlock("mid.block_1.", block_in, block_in)
+        self.mid_attn_1 = AEAttnBlock("mid.attn_1.", block_in)
+        self.mid_block_2 = AEVideoResBlock("mid.block_2.", block_in, block_in)
+        self.up = {}
+        for lvl in reversed(range(nres)):
+            block_out = cfg.ch * cfg.ch_mult[lvl]
+            blocks = []
+            for b in range(cfg.num_res_blocks + 1):
+                blocks.append(AEVideoResBlock(f"up.{lvl}.block.{b}.", block_in, block_out))
+                block_in = block_out
+            ups = _Conv(f"up.{lvl}.upsample.conv.", block_in, block_in, ups=1) if lvl != 0 else None
+            self.up[lvl] = (blocks, ups)
+        self.final_ch = block_in
+        self.conv_out = _Conv("conv_out.", block_in, cfg.out_ch)
+        self.prepared = False
+
+    def _modules(self):
+        yield self.conv_in
+        yield self.mid_block_1
+        yield self.mid_attn_1
+        yield self.mid_block_2
+        for lvl in self.up:
+            blocks, ups = self.up[lvl]
+            yield from blocks
+            if ups is not None:
+                yield ups
+        yield self.conv_out
+
+    def spec(self):
+        s = Spec()
+        for m in self._modules():
+            m.spec(s)
+        s.add("norm_out.weight", self.final_ch); s.add("norm_out.bias", self.final_ch)
+        s.add("conv_out.time_mix_conv.weight", self.cfg.out_ch, self.cfg.out_ch, 3, 1, 1)
+        s.add("conv_out.time_mix_conv.bias", self.cfg.out_ch)
+        return s
+
+    def load_state_dict(self, sd, device="cuda", prefix=""):
+        if prefix:
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        check_state_dict(self.spec(), sd)
+        for m in self._modules():
+            m.prepare(sd, device)
+        self.no = (_dev_f32(sd["norm_out.weight"], device), _dev_f32(sd["norm_out.bias"], device))
+        assert self.cfg.out_ch == 3
+        self.tmw = _dev_f32(sd["conv_out.time_mix_conv.weight"][:, :, :, 0, 0], device)   # [co, ci, kt]
+        self.tmb = _dev_f32(sd["conv_out.time_mix_conv.bias"], device)
+        self.device = device
+        self.prepared = True
+        return self
+
+    def forward(self, z, timesteps=None, clamp=False):
+        n, _, H, W = z.shape
+        assert timesteps is None or timesteps == n, "one call decodes one temporal group (streaming_svd.py:138-146)"
+        F = n
+        h = ops.nchw_to_tokens(z.float().contiguous(), None, None, 32)
+        h, H, W = self.conv_in.forward(h, F, H, W)
+        h = self.mid_block_1.forward(h, F, H, W)
+        h = self.mid_attn_1.forward(h, F, H, W)
+        h = self.mid_block_2.forward(h, F, H, W)
+        for lvl in self.up:
+            blocks, ups = self.up[lvl]
+            for b in blocks:
+                h = b.forward(h, F, H, W)
+            if ups is not None:
+                h, H, W = ups.forward(h, F, H, W)
+        h = ops.groupnorm(h, F, H * W, *self.no, 1e-6, silu=True)
+        h, _, _ = self.conv_out.forward(h, F, H, W, out_f32=True)          # [F*H*W, 4] fp32 (3 valid channels)
+        return ops.ae_time_mix3(h, self.tmw, self.tmb, F, H, W, clamp)       # AE3DConv.time_mix_conv -> NCHW fp32
+
+
+class AutoencodingEngineDecoder:
+    """The slice of AutoencodingEngine the hot path touches: ``decode(z, timesteps=n)`` and ``.decoder``
+    (code/models/svd/sgm/models/autoencoder.py:210-212, diffusion_trainer/streaming_svd.py:138-146)."""
+
+    def __init__(self, decoder):
+        self.decoder = decoder
+
+    def decode(self, z, **kwargs):
+        return self.decoder.forward(z, **kwargs)

@@ -1,0 +1,671 @@
+"""Host-side mirror of the StreamingSVD denoiser networks, executing on the libsvdhip.so kernels.
+
+Mirrors (same names, same state_dict keys, same forward contracts):
+  * VideoResBlock / VideoUNet        <- code/models/diffusion/video_model.py:16-85, 88-618
+  * SpatialVideoTransformer (+ BasicTransformerBlock, VideoTransformerBlock)
+                                     <- code/models/svd/sgm/modules/video_attention.py:23-333, attention.py:464-593,679-804
+  * ConditionalModel (CAM merger)    <- code/models/cam/conditioning.py:7-146
+  * ControlNet (+ cond. embedding)   <- code/models/control/controlnet.py:51-121,124-554
+
+What is different from the reference is the execution plan, not the arithmetic:
+  * activations live channels-last as token matrices [frames*H*W, C] in bf16; there is not a single physical
+    transpose: the "(b t) c h w <-> b c t h w" and "(b t) s c <-> (b s) t c" rearranges of the reference become
+    addressing modes of the kernels (temporal-conv GEMM view, strided temporal attention);
+  * bias / timestep-embedding add / residual / GEGLU / alpha-blend are GEMM epilogues;
+  * cross-attention to the 1-token CLIP context (attn2) is softmax over ONE key == 1, hence
+    attn2(x, ctx) == to_out(to_v(ctx)) exactly: computed as a per-frame vector and folded into the
+    attn1 output epilogue.  Contexts with more than one token (APM, disabled in the shipped config.yaml:115) raise.
+"""
+import math
+
+import torch
+
+from . import ops
+from .params import Spec
+
+BF16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# weight packing helpers (run once in prepare(); torch here is parameter plumbing, not the hot path)
+# ----------------------------------------------------------------------------------------------------------------
+def _dev_bf16(t, dev):
+    return t.detach().to(device=dev, dtype=torch.float32).to(BF16).contiguous()
+
+
+def _dev_f32(t, dev):
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def pack_conv3x3(w, cin_pad=None, cout_pad=None):
+    """[Cout, Cin, 3, 3] -> [Cout(_pad), 9 * Cin(_pad)] with K ordered (ky, kx, c)."""
+    co, ci = w.shape[0], w.shape[1]
+    cp = cin_pad or ci
+    cop = cout_pad or co
+    wp = torch.zeros(cop, 3, 3, cp, dtype=torch.float32, device=w.device)
+    wp[:co, :, :, :ci] = w.detach().float().permute(0, 2, 3, 1)
+    return wp.reshape(cop, 9 * cp)
+
+
+def pack_tconv3(w):
+    """[Cout, Cin, 3, 1, 1] -> [Cout, 3 * Cin] with K ordered (kt, c)."""
+    co, ci = w.shape[0], w.shape[1]
+    return w.detach().float()[:, :, :, 0, 0].permute(0, 2, 1).reshape(co, 3 * ci)
+
+
+def pack_geglu(w, b):
+    """GEGLU proj [2*inner, K]: rows (value | gate) -> interleaved in blocks of 32 rows (v0 g0 v1 g1 ...)."""
+    half = w.shape[0] // 2
+    assert half % 32 == 0
+    K = w.shape[1]
+    w = w.detach().float()
+    b = b.detach().float()
+    wv, wg = w[:half].reshape(half // 32, 32, K), w[half:].reshape(half // 32, 32, K)
+    bv, bg = b[:half].reshape(half // 32, 32), b[half:].reshape(half // 32, 32)
+    return torch.stack([wv, wg], 1).reshape(2 * half, K), torch.stack([bv, bg], 1).reshape(2 * half)
+
+
+def pad_rows(w, n):
+    if w.shape[0] >= n:
+        return w
+    out = torch.zeros((n,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    out[: w.shape[0]] = w
+    return out
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + math.exp(-float(x)))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class VideoResBlock:
+    """ResBlock (2-D) -> time_stack ResBlock (3,1,1) -> AlphaBlender.  video_model.py:66-85, openaimodel.py:328-354."""
+
+    def __init__(self, prefix, cin, cout, emb_ch):
+        self.p, self.cin, self.cout, self.emb_ch = prefix, cin, cout, emb_ch
+
+    def spec(self, s):
+        p, ci, co, e = self.p, self.cin, self.cout, self.emb_ch
+        s.add(p + "in_layers.0.weight", ci); s.add(p + "in_layers.0.bias", ci)
+        s.add(p + "in_layers.2.weight", co, ci, 3, 3); s.add(p + "in_layers.2.bias", co)
+        s.add(p + "emb_layers.1.weight", co, e); s.add(p + "emb_layers.1.bias", co)
+        s.add(p + "out_layers.0.weight", co); s.add(p + "out_layers.0.bias", co)
+        s.add(p + "out_layers.3.weight", co, co, 3, 3); s.add(p + "out_layers.3.bias", co)
+        if ci != co:
+            s.add(p + "skip_connection.weight", co, ci, 1, 1); s.add(p + "skip_connection.bias", co)
+        t = p + "time_stack."
+        s.add(t + "in_layers.0.weight", co); s.add(t + "in_layers.0.bias", co)
+        s.add(t + "in_layers.2.weight", co, co, 3, 1, 1); s.add(t + "in_layers.2.bias", co)
+        s.add(t + "emb_layers.1.weight", co, e); s.add(t + "emb_layers.1.bias", co)
+        s.add(t + "out_layers.0.weight", co); s.add(t + "out_layers.0.bias", co)
+        s.add(t + "out_layers.3.weight", co, co, 3, 1, 1); s.add(t + "out_layers.3.bias", co)
+        s.add(p + "time_mixer.mix_factor", 1)
+
+    def prepare(self, sd, dev):
+        p = self.p
+        g = lambda k: sd[p + k]
+        self.n1w, self.n1b = _dev_f32(g("in_layers.0.weight"), dev), _dev_f32(g("in_layers.0.bias"), dev)
+        self.w1, self.b1 = _dev_bf16(pack_conv3x3(g("in_layers.2.weight")), dev), _dev_f32(g("in_layers.2.bias"), dev)
+        self.we, self.be = _dev_bf16(g("emb_layers.1.weight"), dev), _dev_f32(g("emb_layers.1.bias"), dev)
+        self.n2w, self.n2b = _dev_f32(g("out_layers.0.weight"), dev), _dev_f32(g("out_layers.0.bias"), dev)
+        self.w2, self.b2 = _dev_bf16(pack_conv3x3(g("out_layers.3.weight")), dev), _dev_f32(g("out_layers.3.bias"), dev)
+        if self.cin != self.cout:
+            self.ws = _dev_bf16(g("skip_connection.weight")[:, :, 0, 0], dev)
+            self.bs = _dev_f32(g("skip_connection.bias"), dev)
+        t = "time_stack."
+        self.tn1w, self.tn1b = _dev_f32(g(t + "in_layers.0.weight"), dev), _dev_f32(g(t + "in_layers.0.bias"), dev)
+        self.tw1, self.tb1 = _dev_bf16(pack_tconv3(g(t + "in_layers.2.weight")), dev), _dev_f32(g(t + "in_layers.2.bias"), dev)
+        self.twe, self.tbe = _dev_bf16(g(t + "emb_layers.1.weight"), dev), _dev_f32(g(t + "emb_layers.1.bias"), dev)
+        self.tn2w, self.tn2b = _dev_f32(g(t + "out_layers.0.weight"), dev), _dev_f32(g(t + "out_layers.0.bias"), dev)
+        self.tw2, self.tb2 = _dev_bf16(pack_tconv3(g(t + "out_layers.3.weight")), dev), _dev_f32(g(t + "out_layers.3.bias"), dev)
+        self.alpha = _sigmoid(g("time_mixer.mix_factor"))   # image_only_indicator == 0 (util.py:341-357)
+
+    def forward(self, x, emb_silu, F, T, H, W):
+        pix = H * W
+        cv_in = dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F)
+        cv = dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F)
+        tv = dict(cin=self.cout, T=T, pix=pix)
+        h = ops.groupnorm(x, F, pix, self.n1w, self.n1b, 1e-5, silu=True)
+        e = ops.gemm(emb_silu, self.we, bias=self.be, out_f32=True)
+        h = ops.gemm(h, self.w1, bias=self.b1, rowvec=e, rows_per_vec=pix, conv=cv_in)
+        h = ops.groupnorm(h, F, pix, self.n2w, self.n2b, 1e-5, silu=True)
+        skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
+        hs = ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=cv)
+        # time_stack: 5-D GroupNorm statistics pool over the T frames of a batch element (video_model.py:75-80)
+        g = ops.groupnorm(hs, F, pix, self.tn1w, self.tn1b, 1e-5, frames_per_stat=T, silu=True)
+        et = ops.gemm(emb_silu, self.twe, bias=self.tbe, out_f32=True)
+        g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pix, temporal=tv)
+        g = ops.groupnorm(g, F, pix, self.tn2w, self.tn2b, 1e-5, frames_per_stat=T, silu=True)
+        # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip)
+        return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(self.alpha, hs), temporal=tv)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _Attn1:
+    """Parameters of a self-attention (to_q/to_k/to_v no bias, to_out.0 with bias)."""
+
+    @staticmethod
+    def spec(s, p, c):
+        for n in ("to_q", "to_k", "to_v"):
+            s.add(p + n + ".weight", c, c)
+        s.add(p + "to_out.0.weight", c, c); s.add(p + "to_out.0.bias", c)
+
+
+def _spec_attn2(s, p, c, ctx):
+    s.add(p + "to_q.weight", c, c)
+    s.add(p + "to_k.weight", c, ctx); s.add(p + "to_v.weight", c, ctx)
+    s.add(p + "to_out.0.weight", c, c); s.add(p + "to_out.0.bias", c)
+
+
+def _spec_ln(s, p, c):
+    s.add(p + ".weight", c); s.add(p + ".bias", c)
+
+
+def _spec_ff(s, p, c):
+    s.add(p + "net.0.proj.weight", 8 * c, c); s.add(p + "net.0.proj.bias", 8 * c)
+    s.add(p + "net.2.weight", c, 4 * c); s.add(p + "net.2.bias", c)
+
+
+class SpatialVideoTransformer:
+    """video_attention.py:174-333 with depth 1, use_linear, ff_in, use_spatial_context (config.yaml:99-113)."""
+
+    def __init__(self, prefix, ch, ctx_dim):
+        assert ch % 64 == 0
+        self.p, self.c, self.ctx, self.heads = prefix, ch, ctx_dim, ch // 64
+        self._vt = {}
+        self._temb = {}
+
+    def spec(self, s):
+        p, c, ctx = self.p, self.c, self.ctx
+        _spec_ln(s, p + "norm", c)
+        s.add(p + "proj_in.weight", c, c); s.add(p + "proj_in.bias", c)
+        b = p + "transformer_blocks.0."
+        _Attn1.spec(s, b + "attn1.", c)
+        _spec_ff(s, b + "ff.", c)
+        _spec_attn2(s, b + "attn2.", c, ctx)
+        for n in ("norm1", "norm2", "norm3"):
+            _spec_ln(s, b + n, c)
+        s.add(p + "proj_out.weight", c, c); s.add(p + "proj_out.bias", c)
+        t = p + "time_stack.0."
+        _spec_ln(s, t + "norm_in", c)
+        _spec_ff(s, t + "ff_in.", c)
+        _Attn1.spec(s, t + "attn1.", c)
+        _spec_ff(s, t + "ff.", c)
+        _spec_ln(s, t + "norm2", c)
+        _spec_attn2(s, t + "attn2.", c, ctx)
+        _spec_ln(s, t + "norm1", c)
+        _spec_ln(s, t + "norm3", c)
+        s.add(p + "time_pos_embed.0.weight", 4 * c, c); s.add(p + "time_pos_embed.0.bias", 4 * c)
+        s.add(p + "time_pos_embed.2.weight", c, 4 * c); s.add(p + "time_pos_embed.2.bias", c)
+        s.add(p + "time_mixer.mix_factor", 1)
+
+    def prepare(self, sd, dev):
+        p = self.p
+        g = lambda k: sd[p + k]
+        W = lambda k: _dev_bf16(g(k), dev)
+        Fv = lambda k: _dev_f32(g(k), dev)
+        self.dev = dev
+        self.nw, self.nb = Fv("norm.weight"), Fv("norm.bias")
+        self.wpi, self.bpi = W("proj_in.weight"), Fv("proj_in.bias")
+        self.wpo, self.bpo = W("proj_out.weight"), Fv("proj_out.bias")
+        b = "transformer_blocks.0."
+        self.s_ln = {n: (Fv(b + n + ".weight"), Fv(b + n + ".bias")) for n in ("norm1", "norm3")}
+        self.s_wqk = _dev_bf16(torch.cat([g(b + "attn1.to_q.weight"), g(b + "attn1.to_k.weight")], 0), dev)
+        self.s_wv = W(b + "attn1.to_v.weight")
+        self.s_wo, self.s_bo = W(b + "attn1.to_out.0.weight"), Fv(b + "attn1.to_out.0.bias")
+        self.s_wv2, self.s_wo2, self.s_bo2 = W(b + "attn2.to_v.weight"), W(b + "attn2.to_out.0.weight"), Fv(b + "attn2.to_out.0.bias")
+        w1, b1 = pack_geglu(g(b + "ff.net.0.proj.weight"), g(b + "ff.net.0.proj.bias"))
+        self.s_wf1, self.s_bf1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
+        self.s_wf2, self.s_bf2 = W(b + "ff.net.2.weight"), Fv(b + "ff.net.2.bias")
+        t = "time_stack.0."
+        self.t_ln = {n: (Fv(t + n + ".weight"), Fv(t + n + ".bias")) for n in ("norm_in", "norm1", "norm3")}
+        w1, b1 = pack_geglu(g(t + "ff_in.net.0.proj.weight"), g(t + "ff_in.net.0.proj.bias"))
+        self.t_wi1, self.t_bi1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
+        self.t_wi2, self.t_bi2 = W(t + "ff_in.net.2.weight"), Fv(t + "ff_in.net.2.bias")
+        self.t_wqkv = _dev_bf16(torch.cat([g(t + "attn1.to_q.weight"), g(t + "attn1.to_k.weight"), g(t + "attn1.to_v.weight")], 0), dev)
+        self.t_wo, self.t_bo = W(t + "attn1.to_out.0.weight"), Fv(t + "attn1.to_out.0.bias")
+        self.t_wv2, self.t_wo2, self.t_bo2 = W(t + "attn2.to_v.weight"), W(t + "attn2.to_out.0.weight"), Fv(t + "attn2.to_out.0.bias")
+        w1, b1 = pack_geglu(g(t + "ff.net.0.proj.weight"), g(t + "ff.net.0.proj.bias"))
+        self.t_wf1, self.t_bf1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
+        self.t_wf2, self.t_bf2 = W(t + "ff.net.2.weight"), Fv(t + "ff.net.2.bias")
+        self.tp_w0, self.tp_b0 = W("time_pos_embed.0.weight"), Fv("time_pos_embed.0.bias")
+        self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
+        self.alpha = _sigmoid(g("time_mixer.mix_factor"))
+
+    def _vt_buf(self, F, pix):
+        """V^T staging buffer [F, C, tok_ld]; the pad beyond `pix` stays zero (never written by the GEMM)."""
+        tok_ld = (pix + 63) // 64 * 64
+        key = (F, tok_ld)
+        b = self._vt.get(key)
+        if b is None:
+            b = torch.zeros((F, self.c, tok_ld), dtype=BF16, device=self.dev)
+            self._vt[key] = b
+        return b, tok_ld
+
+    def _time_emb(self, F, T):
+        """time_pos_embed(timestep_embedding(arange(T))) repeated per batch element -> [F, C] fp32
+        (video_attention.py:298-308); input independent, cached."""
+        key = (F, T)
+        e = self._temb.get(key)
+        if e is None:
+            idx = torch.arange(T, device=self.dev, dtype=torch.float32)
+            te = ops.timestep_embedding(idx, self.c)
+            h = ops.gemm(te, self.tp_w0, bias=self.tp_b0, silu=True)
+            e1 = ops.gemm(h, self.tp_w2, bias=self.tp_b2, out_f32=True)   # [T, C]
+            e = e1.repeat(F // T, 1).contiguous()
+            self._temb[key] = e
+        return e
+
+    def forward(self, x, ctx, tctx, F, T, H, W):
+        """x [F*H*W, C]; ctx [F, ctx_dim] bf16 (per-frame CLIP token); tctx [F//T, ctx_dim] (= context[::T])."""
+        c, heads, pix = self.c, self.heads, H * W
+        M, B = F * pix, F // T
+        h = ops.groupnorm(x, F, pix, self.nw, self.nb, 1e-6, silu=False)
+        h = ops.gemm(h, self.wpi, bias=self.bpi)
+        # ---- spatial BasicTransformerBlock (attention.py:567-593) ----
+        n1 = ops.layernorm(h, *self.s_ln["norm1"])
+        qk = ops.gemm(n1, self.s_wqk)
+        vt, tok_ld = self._vt_buf(F, pix)
+        ops.gemm(n1, self.s_wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
+        a = torch.empty((M, c), dtype=BF16, device=x.device)
+        ops.attn_spatial(qk[:, :c], qk[:, c:], vt, a, F, pix, heads)
+        v2 = ops.gemm(ops.gemm(ctx, self.s_wv2), self.s_wo2, bias=self.s_bo2, out_f32=True)      # attn2 == const/frame
+        h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h)
+        n3 = ops.layernorm(h, *self.s_ln["norm3"])
+        g = ops.gemm(n3, self.s_wf1, bias=self.s_bf1, geglu=True)
+        h = ops.gemm(g, self.s_wf2, bias=self.s_bf2, residual=h)          # x_spatial
+        # ---- temporal VideoTransformerBlock on the same token layout (video_attention.py:125-168) ----
+        nin, xm = ops.layernorm(h, *self.t_ln["norm_in"], addvec=self._time_emb(F, T), rows_per_vec=pix, want_sum=True)
+        g = ops.gemm(nin, self.t_wi1, bias=self.t_bi1, geglu=True)
+        xm = ops.gemm(g, self.t_wi2, bias=self.t_bi2, residual=xm)
+        n1 = ops.layernorm(xm, *self.t_ln["norm1"])
+        qkv = ops.gemm(n1, self.t_wqkv)
+        at = torch.empty((M, c), dtype=BF16, device=x.device)
+        ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pix, heads)
+        v2t = ops.gemm(ops.gemm(tctx, self.t_wv2), self.t_wo2, bias=self.t_bo2, out_f32=True)    # [B, C]
+        xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pix, residual=xm)
+        n3 = ops.layernorm(xm, *self.t_ln["norm3"])
+        g = ops.gemm(n3, self.t_wf1, bias=self.t_bf1, geglu=True)
+        xb = ops.gemm(g, self.t_wf2, bias=self.t_bf2, residual=xm, blend=(self.alpha, h))     # AlphaBlender
+        return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class ConditionalModel:
+    """CAM merger: per-pixel temporal cross-attention of T sample frames to Tc ControlNet frames.
+    conditioning.py:39-81,117-146 (+ diffusers Attention: to_q/k/v no bias, to_out.0 bias, heads = C/64)."""
+
+    def __init__(self, prefix, ch):
+        self.p, self.c, self.heads = prefix + "temporal_transformer.", ch, ch // 64
+
+    def spec(self, s):
+        p, c = self.p, self.c
+        _Attn1.spec(s, p + "attention.", c)
+        _spec_ln(s, p + "norm", c)
+        s.add(p + "proj_in.weight", c, c); s.add(p + "proj_in.bias", c)
+        s.add(p + "proj_out.weight", c, c); s.add(p + "proj_out.bias", c)
+
+    def prepare(self, sd, dev):
+        p = self.p
+        g = lambda k: sd[p + k]
+        self.nw, self.nb = _dev_f32(g("norm.weight"), dev), _dev_f32(g("norm.bias"), dev)
+        self.wpi, self.bpi = _dev_bf16(g("proj_in.weight"), dev), _dev_f32(g("proj_in.bias"), dev)
+        self.wpo, self.bpo = _dev_bf16(g("proj_out.weight"), dev), _dev_f32(g("proj_out.bias"), dev)
+        self.wq = _dev_bf16(g("attention.to_q.weight"), dev)
+        self.wkv = _dev_bf16(torch.cat([g("attention.to_k.weight"), g("attention.to_v.weight")], 0), dev)
+        self.wo, self.bo = _dev_bf16(g("attention.to_out.0.weight"), dev), _dev_f32(g("attention.to_out.0.bias"), dev)
+
+    def forward(self, sample, cond, F, T, Tc, H, W):
+        c, pix = self.c, H * W
+        B = F // T
+        hn = ops.groupnorm(sample, F, pix, self.nw, self.nb, 1e-6, frames_per_stat=T, silu=False)
+        hn = ops.gemm(hn, self.wpi, bias=self.bpi)
+        q = ops.gemm(hn, self.wq)
+        kv = ops.gemm(cond, self.wkv)
+        a = torch.empty((F * pix, c), dtype=BF16, device=sample.device)
+        ops.attn_temporal(q, kv[:, :c], kv[:, c:], a, B, T, Tc, pix, self.heads)
+        a = ops.gemm(a, self.wo, bias=self.bo)
+        # dropout(p=.25) on the non-conditional frames is identity in eval mode (conditioning.py:74-75)
+        return ops.gemm(a, self.wpo, bias=self.bpo, residual=sample)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _Conv:
+    """3x3 conv (stem / Downsample.op / Upsample.conv / out) as implicit GEMM."""
+
+    def __init__(self, prefix, cin, cout, stride=1, ups=0):
+        self.p, self.cin, self.cout, self.stride, self.ups = prefix, cin, cout, stride, ups
+        self.cin_pad = cin if cin % 32 == 0 else (cin + 31) // 32 * 32
+        self.cout_pad = cout if cout % 4 == 0 else (cout + 3) // 4 * 4
+
+    def spec(self, s):
+        s.add(self.p + "weight", self.cout, self.cin, 3, 3); s.add(self.p + "bias", self.cout)
+
+    def prepare(self, sd, dev):
+        self.w = _dev_bf16(pack_conv3x3(sd[self.p + "weight"], self.cin_pad, self.cout_pad), dev)
+        self.b = _dev_f32(pad_rows(sd[self.p + "bias"].detach().float(), self.cout_pad), dev)
+
+    def forward(self, x, F, H, W, **kw):
+        if self.stride == 2:
+            ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        elif self.ups:
+            ho, wo = 2 * H, 2 * W
+        else:
+            ho, wo = H, W
+        cv = dict(cin=self.cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=self.stride, ups=self.ups, frames=F)
+        return ops.gemm(x, self.w, bias=self.b, conv=cv, **kw), ho, wo
+
+
+class _EmbedMLP:
+    """Linear -> SiLU -> Linear (time_embed / label_emb.0)."""
+
+    def __init__(self, prefix, cin, cmid, cout):
+        self.p, self.cin, self.cmid, self.cout = prefix, cin, cmid, cout
+
+    def spec(self, s):
+        s.add(self.p + "0.weight", self.cmid, self.cin); s.add(self.p + "0.bias", self.cmid)
+        s.add(self.p + "2.weight", self.cout, self.cmid); s.add(self.p + "2.bias", self.cout)
+
+    def prepare(self, sd, dev):
+        self.w0, self.b0 = _dev_bf16(sd[self.p + "0.weight"], dev), _dev_f32(sd[self.p + "0.bias"], dev)
+        self.w2, self.b2 = _dev_bf16(sd[self.p + "2.weight"], dev), _dev_f32(sd[self.p + "2.bias"], dev)
+
+    def forward(self, x_bf16, add=None):
+        h = ops.gemm(x_bf16, self.w0, bias=self.b0, silu=True)
+        return ops.gemm(h, self.w2, bias=self.b2, rowvec=add, rows_per_vec=1, out_f32=True)
+
+
+class UNetConfig:
+    """Hyper-parameters of config.yaml:69-115 (network_config)."""
+
+    def __init__(self, in_channels=8, model_channels=320, out_channels=4, num_res_blocks=2,
+                 attention_resolutions=(4, 2, 1), channel_mult=(1, 2, 4, 4), context_dim=1024, adm_in_channels=768,
+                 num_head_channels=64, controlnet_mode=True,
+                 conditioning_embedding_out_channels=(32, 96, 256, 512)):
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions = num_res_blocks, tuple(attention_resolutions)
+        self.channel_mult, self.context_dim, self.adm_in_channels = tuple(channel_mult), context_dim, adm_in_channels
+        self.num_head_channels, self.controlnet_mode = num_head_channels, controlnet_mode
+        self.conditioning_embedding_out_channels = tuple(conditioning_embedding_out_channels)
+        assert num_head_channels == 64, "kernels are specialised for head dim 64 (config.yaml:93)"
+
+
+class _EncoderBase:
+    """Shared encoder half (time/label embedding, input_blocks, middle_block) of VideoUNet and ControlNet."""
+
+    def _build_encoder(self, cfg):
+        mc, emb = cfg.model_channels, cfg.model_channels * 4
+        self.cfg, self.mc, self.emb_ch = cfg, mc, emb
+        self.time_embed = _EmbedMLP("time_embed.", mc, emb, emb)
+        self.label_emb = _EmbedMLP("label_emb.0.", cfg.adm_in_channels, emb, emb)
+        self.input_blocks = [[_Conv("input_blocks.0.0.", cfg.in_channels, mc)]]
+        self.input_block_chans = [mc]
+        ch, ds, idx = mc, 1, 1
+        for level, mult in enumerate(cfg.channel_mult):
+            for _ in range(cfg.num_res_blocks):
+                layers = [VideoResBlock(f"input_blocks.{idx}.0.", ch, mult * mc, emb)]
+                ch = mult * mc
+                if ds in cfg.attention_resolutions:
+                    layers.append(SpatialVideoTransformer(f"input_blocks.{idx}.1.", ch, cfg.context_dim))
+                self.input_blocks.append(layers)
+                self.input_block_chans.append(ch)
+                idx += 1
+            if level != len(cfg.channel_mult) - 1:
+                self.input_blocks.append([_Conv(f"input_blocks.{idx}.0.op.", ch, ch, stride=2)])
+                self.input_block_chans.append(ch)
+                idx += 1
+                ds *= 2
+        self.middle_block = [VideoResBlock("middle_block.0.", ch, ch, emb),
+                             SpatialVideoTransformer("middle_block.1.", ch, cfg.context_dim),
+                             VideoResBlock("middle_block.2.", ch, ch, emb)]
+        self._enc_ch, self._enc_ds = ch, ds
+
+    def _embed(self, timesteps, y):
+        t_emb = ops.timestep_embedding(timesteps, self.mc)
+        emb = self.time_embed.forward(t_emb)
+        emb = self.label_emb.forward(ops.to_bf16(y), add=emb)      # emb + label_emb(y)
+        return ops.to_bf16(emb, silu=True)                          # every emb_layers starts with SiLU
+
+    @staticmethod
+    def _run(layers, h, emb_silu, ctx, tctx, F, T, H, W):
+        for m in layers:
+            if isinstance(m, VideoResBlock):
+                h = m.forward(h, emb_silu, F, T, H, W)
+            elif isinstance(m, SpatialVideoTransformer):
+                h = m.forward(h, ctx, tctx, F, T, H, W)
+            else:
+                h, H, W = m.forward(h, F, H, W)
+        return h, H, W
+
+    @staticmethod
+    def _contexts(context, T):
+        Fn = context.shape[0]
+        if context.dim() == 3:
+            if context.shape[1] != 1:
+                raise NotImplementedError("cross-attention contexts with >1 token (APM) are outside the shipped "
+                                          "configuration (config.yaml:115 use_apm: false)")
+            context = context[:, 0]
+        ctx = ops.to_bf16(context.float().contiguous())
+        tctx = ops.to_bf16(context[::T].float().contiguous())       # time_context = context[::T]
+        return ctx, tctx
+
+
+class VideoUNet(_EncoderBase):
+    """video_model.py:88-618.  forward() keeps the reference signature; tensors in/out are NCHW fp32."""
+
+    def __init__(self, cfg=None):
+        cfg = cfg or UNetConfig()
+        self._build_encoder(cfg)
+        mc, emb = self.mc, self.emb_ch
+        self.controlnet_mode = cfg.controlnet_mode
+        self.in_channels, self.model_channels, self.out_channels = cfg.in_channels, mc, cfg.out_channels
+        if cfg.controlnet_mode:
+            self.cross_attention_merger_input_blocks = [
+                ConditionalModel(f"cross_attention_merger_input_blocks.{i}.", c) for i, c in enumerate(self.input_block_chans)]
+            self.cross_attention_merger_mid_block = ConditionalModel("cross_attention_merger_mid_block.", self._enc_ch)
+        self.output_blocks = []
+        chans = list(self.input_block_chans)
+        ch, ds, idx = self._enc_ch, self._enc_ds, 0
+        for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+            for i in range(cfg.num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [VideoResBlock(f"output_blocks.{idx}.0.", ch + ich, mc * mult, emb)]
+                ch = mc * mult
+                if ds in cfg.attention_resolutions:
+                    layers.append(SpatialVideoTransformer(f"output_blocks.{idx}.1.", ch, cfg.context_dim))
+                if level and i == cfg.num_res_blocks:
+                    layers.append(_Conv(f"output_blocks.{idx}.{len(layers)}.conv.", ch, ch, ups=1))
+                    ds //= 2
+                self.output_blocks.append(layers)
+                idx += 1
+        self.out_conv = _Conv("out.2.", mc, cfg.out_channels)
+        self.prepared = False
+
+    def _modules(self):
+        for blk in self.input_blocks:
+            yield from blk
+        yield from self.middle_block
+        for blk in self.output_blocks:
+            yield from blk
+        if self.controlnet_mode:
+            yield from self.cross_attention_merger_input_blocks
+            yield self.cross_attention_merger_mid_block
+        yield self.time_embed
+        yield self.label_emb
+        yield self.out_conv
+
+    def spec(self):
+        s = Spec()
+        for m in self._modules():
+            m.spec(s)
+        s.add("out.0.weight", self.mc); s.add("out.0.bias", self.mc)
+        return s
+
+    def load_state_dict(self, sd, device="cuda", prefix=""):
+        if prefix:
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        from .params import check_state_dict
+        check_state_dict(self.spec(), sd)
+        for m in self._modules():
+            m.prepare(sd, device)
+        self.ow, self.ob = _dev_f32(sd["out.0.weight"], device), _dev_f32(sd["out.0.bias"], device)
+        self.device = device
+        self.prepared = True
+        return self
+
+    def forward_tokens(self, x_tok, timesteps, context, y, T, H, W, hs_control_input=None, hs_control_mid=None,
+                       num_conditional_frames=None):
+        """x_tok [F*H*W, 32] bf16 (8 latent channels zero-padded to 32).  Returns [F*H*W, 4] fp32 tokens."""
+        F = timesteps.numel()
+        emb_silu = self._embed(timesteps, y)
+        ctx, tctx = self._contexts(context, T)
+        hs = []
+        h = x_tok
+        for blk in self.input_blocks:
+            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W)
+            hs.append((h, H, W))
+        if hs_control_input is not None:
+            # CAM: merge ControlNet features into every skip tensor (video_model.py:582-591)
+            assert len(hs) == len(hs_control_input) == len(self.cross_attention_merger_input_blocks)
+            Tc = num_conditional_frames
+            hs = [(mg.forward(hh, hc, F, T, Tc, Hh, Wh), Hh, Wh)
+                  for (hh, Hh, Wh), hc, mg in zip(hs, hs_control_input, self.cross_attention_merger_input_blocks)]
+        # middle_block consumes the UN-merged encoder output (video_model.py:593-600)
+        h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W)
+        if hs_control_mid is not None:
+            h = self.cross_attention_merger_mid_block.forward(h, hs_control_mid, F, T, num_conditional_frames, H, W)
+        for blk in self.output_blocks:
+            skip, Hs, Ws = hs.pop()
+            assert (Hs, Ws) == (H, W)
+            h = ops.concat_channels(h, skip)
+            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W)
+        h = ops.groupnorm(h, F, H * W, self.ow, self.ob, 1e-5, silu=True)
+        out, _, _ = self.out_conv.forward(h, F, H, W, out_f32=True)
+        return out
+
+    def forward(self, x, timesteps, context=None, y=None, time_context=None, num_video_frames=None,
+                num_conditional_frames=None, image_only_indicator=None, hs_control_input=None, hs_control_mid=None):
+        """Reference signature (video_model.py:540-556).  x [(B T), 8, H, W] fp32 -> [(B T), 4, H, W] fp32."""
+        assert time_context is None and y is not None
+        if image_only_indicator is not None and bool(image_only_indicator.any()):
+            raise NotImplementedError("image_only_indicator != 0 (AlphaBlender 'where' branch) is unused by StreamingSVD")
+        F, _, H, W = x.shape
+        x_tok = ops.nchw_to_tokens(x.float().contiguous(), None, None, 32)
+        out = self.forward_tokens(x_tok, timesteps.float().contiguous(), context, y.float().contiguous(),
+                                  num_video_frames, H, W, hs_control_input, hs_control_mid, num_conditional_frames)
+        return ops.tokens_to_nchw(out, self.out_channels, F, H, W)
+
+
+class ControlNetConditioningEmbedding:
+    """controlnet.py:51-121 with use_normalization (per-pixel LayerNorm) and stride-2 downsampling."""
+
+    def __init__(self, prefix, out_ch, block_out=(32, 96, 256, 512)):
+        self.p, self.out_ch, self.bo = prefix, out_ch, tuple(block_out)
+        self.conv_in = _Conv(prefix + "conv_in.", 3, block_out[0])
+        self.blocks = []
+        for i in range(len(block_out) - 1):
+            self.blocks.append(_Conv(prefix + f"blocks.{2 * i}.", block_out[i], block_out[i]))
+            self.blocks.append(_Conv(prefix + f"blocks.{2 * i + 1}.", block_out[i], block_out[i + 1], stride=2))
+        self.conv_out = _Conv(prefix + "conv_out.", block_out[-1], out_ch)
+
+    def spec(self, s):
+        self.conv_in.spec(s)
+        for b in self.blocks:
+            b.spec(s)
+        for i, b in enumerate(self.blocks):
+            _spec_ln(s, self.p + f"norms.{i}", b.cout)
+        self.conv_out.spec(s)
+
+    def prepare(self, sd, dev):
+        self.conv_in.prepare(sd, dev)
+        self.conv_out.prepare(sd, dev)
+        self.norms = []
+        for i, b in enumerate(self.blocks):
+            b.prepare(sd, dev)
+            self.norms.append((_dev_f32(sd[self.p + f"norms.{i}.weight"], dev), _dev_f32(sd[self.p + f"norms.{i}.bias"], dev)))
+
+    def forward(self, cond_nchw):
+        """cond [Fc, 3, 8H, 8W] fp32 in [-1,1] -> tokens [Fc*H*W, out_ch]."""
+        Fc, _, H, W = cond_nchw.shape
+        h = ops.nchw_to_tokens(cond_nchw.float().contiguous(), None, None, 32)
+        h, H, W = self.conv_in.forward(h, Fc, H, W, silu=True)
+        for b, (nw, nb) in zip(self.blocks, self.norms):
+            h, H, W = b.forward(h, Fc, H, W)
+            h = ops.layernorm(h, nw, nb, silu=True)
+        h, H, W = self.conv_out.forward(h, Fc, H, W)
+        return h, H, W
+
+
+class ControlNet(_EncoderBase):
+    """controlnet.py:124-554: encoder half of the UNet on the conditioning frames + image-condition embedding."""
+
+    def __init__(self, cfg=None):
+        cfg = cfg or UNetConfig()
+        self._build_encoder(cfg)
+        assert cfg.model_channels == 320, "reference hard-codes the cond-embedding width to 320 (controlnet.py:443-446)"
+        self.controlnet_cond_embedding = ControlNetConditioningEmbedding(
+            "controlnet_cond_embedding.", 320, cfg.conditioning_embedding_out_channels)
+        self.prepared = False
+        self._cond_cache = None
+
+    @classmethod
+    def from_unet(cls, unet, **_ignored):
+        return cls(unet.cfg)
+
+    def _modules(self):
+        for blk in self.input_blocks:
+            yield from blk
+        yield from self.middle_block
+        yield self.time_embed
+        yield self.label_emb
+        yield self.controlnet_cond_embedding
+
+    def spec(self):
+        s = Spec()
+        for m in self._modules():
+            m.spec(s)
+        return s
+
+    def load_state_dict(self, sd, device="cuda", prefix=""):
+        if prefix:
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        from .params import check_state_dict
+        check_state_dict(self.spec(), sd)
+        for m in self._modules():
+            m.prepare(sd, device)
+        self.device = device
+        self.prepared = True
+        return self
+
+    def embed_condition(self, controlnet_cond):
+        """The image-condition embedding depends only on ctrl_frames, not on sigma: it is computed once per
+        distinct input tensor and reused across the Euler steps of a chunk (the reference recomputes it every
+        step, controlnet.py:520; the values are identical)."""
+        key = (controlnet_cond.data_ptr(), tuple(controlnet_cond.shape), controlnet_cond._version)
+        if self._cond_cache is None or self._cond_cache[0] != key:
+            self._cond_cache = (key, self.controlnet_cond_embedding.forward(controlnet_cond)[0])
+        return self._cond_cache[1]
+
+    def forward_tokens(self, x_tok, timesteps, controlnet_cond, context, y, T, H, W):
+        F = timesteps.numel()
+        emb_silu = self._embed(timesteps, y)
+        ctx, tctx = self._contexts(context, T)
+        cond = self.embed_condition(controlnet_cond)
+        hs = []
+        h = x_tok
+        for i, blk in enumerate(self.input_blocks):
+            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W)
+            if i == 0:
+                h = ops.add_rows(h, cond)          # Merger 'addition', frame_expansion none (controlnet.py:23-48)
+            hs.append(h)
+        h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W)
+        return hs, h
+
+    def forward(self, x, timesteps, controlnet_cond, context=None, y=None, time_context=None, num_video_frames=None,
+                num_video_frames_conditional=None, image_only_indicator=None):
+        """Reference signature (controlnet.py:496-507); returns token tensors (consumed by VideoUNet's CAM mergers)."""
+        assert num_video_frames == num_video_frames_conditional
+        F, _, H, W = x.shape
+        x_tok = ops.nchw_to_tokens(x.float().contiguous(), None, None, 32)
+        return self.forward_tokens(x_tok, timesteps.float().contiguous(), controlnet_cond, context,
+                                   y.float().contiguous(), num_video_frames, H, W)

@@ -1,0 +1,92 @@
+"""StreamingWrapper: the drop-in boundary of the denoising hot path.
+
+Mirrors code/models/diffusion/wrappers.py:7-78 -- same constructor arguments, same
+``forward(x, t, c, *, batch_size, num_video_frames, image_only_indicator, ctrl_frames)`` contract, NCHW fp32
+tensors in and out -- so it can take the place of ``model`` in ``Denoiser.forward`` (denoiser.py:36-38).
+"""
+import torch
+
+from . import ops
+
+
+class StreamingWrapper:
+    def __init__(self, diffusion_model, controlnet, num_frame_conditioning, compile_model=False,
+                 pipeline_offloading=False):
+        if pipeline_offloading:
+            raise NotImplementedError("Pipeline offloading for StreamingI2V not implemented yet.")   # wrappers.py:19-21
+        self.diffusion_model = diffusion_model
+        self.controlnet = controlnet
+        self.num_frame_conditioning = num_frame_conditioning
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- shared core on token tensors ------------------------------------------------------------------------
+    def _run(self, x_tok, t, context, y, batch_size, T, H, W, ctrl_frames):
+        Tc = self.num_frame_conditioning
+        hs_c = mid_c = None
+        if self.diffusion_model.controlnet_mode:
+            # ControlNet sees the first Tc frames of each CFG half (wrappers.py:28-42) ...
+            pix = H * W
+
+            def reduce_rows(v, per):           # "(B F) ... -> B F ..." [:, :Tc]
+                v = v.reshape(batch_size, T * per, *v.shape[1:])[:, :Tc * per]
+                return v.reshape(batch_size * Tc * per, *v.shape[2:]).contiguous()
+
+            x_ctrl = reduce_rows(x_tok, pix)
+            t_ctrl = reduce_rows(t, 1)
+            ctx_ctrl = reduce_rows(context[:, :1], 1)                 # only CLIP token 0 (wrappers.py:39)
+            y_ctrl = reduce_rows(y, 1)
+            # ... and the pixel-space control frames, repeated for both CFG halves (wrappers.py:45-48)
+            cond = ctrl_frames.repeat(2, *([1] * (ctrl_frames.dim() - 1))).flatten(0, 1)
+            cond = self._cond_cached(ctrl_frames, cond)
+            hs_c, mid_c = self.controlnet.forward_tokens(x_ctrl, t_ctrl, cond, ctx_ctrl, y_ctrl, Tc, H, W)
+        return self.diffusion_model.forward_tokens(x_tok, t, context, y, T, H, W, hs_c, mid_c, Tc)
+
+    def _cond_cached(self, ctrl_frames, cond):
+        # keep ONE repeated tensor per ctrl_frames object so ControlNet.embed_condition can recognise it
+        key = (ctrl_frames.data_ptr(), tuple(ctrl_frames.shape), ctrl_frames._version)
+        if getattr(self, "_cond_key", None) != key:
+            self._cond_key, self._cond_val = key, cond.float().contiguous()
+        return self._cond_val
+
+    # ---- reference-shaped entry point ------------------------------------------------------------------------
+    def forward(self, x, t, c, **kwargs):
+        batch_size = kwargs.pop("batch_size")
+        T = kwargs.pop("num_video_frames")
+        ioi = kwargs.pop("image_only_indicator", None)
+        if ioi is not None and bool(ioi.any()):
+            raise NotImplementedError("image_only_indicator != 0 is unused by StreamingSVD (streaming_svd.py:206)")
+        ctrl_frames = kwargs.get("ctrl_frames")
+        F, _, H, W = x.shape
+        concat = c.get("concat")
+        x_tok = ops.nchw_to_tokens(x.float().contiguous(), concat.float().contiguous() if concat is not None else None,
+                                   None, 32)
+        out = self._run(x_tok, t.float().contiguous(), c["crossattn"].float(), c["vector"].float().contiguous(),
+                        batch_size, T, H, W, ctrl_frames)
+        return ops.tokens_to_nchw(out, self.diffusion_model.out_channels, F, H, W)
+
+    __call__ = forward
+
+    # ---- fused entry point used by our EulerEDMSampler ---------------------------------------------------------
+    def forward_fused(self, x, c_in, c_noise, c2, *, batch_size, num_video_frames, ctrl_frames=None,
+                      image_only_indicator=None, **_ignored):
+        """x [T,4,h,w] fp32 (UNscaled sampler state); c2: CFG-doubled cond dict.  Returns raw network output tokens
+        [2T*h*w, 4] fp32 for (uncond | cond), i.e. network(cat([x]*2) * c_in, c_noise, c2)."""
+        T, _, H, W = x.shape
+        key = (x.device, T)
+        aux = getattr(self, "_aux", {}).get(key)
+        if aux is None:
+            aux = (torch.empty((2 * T,), dtype=torch.float32, device=x.device),
+                   torch.empty((2 * T,), dtype=torch.float32, device=x.device))
+            self._aux = getattr(self, "_aux", {})
+            self._aux[key] = aux
+        scale, tvec = aux
+        scale.fill_(c_in)
+        tvec.fill_(c_noise)
+        x2 = torch.cat([x, x], 0)
+        x_tok = ops.nchw_to_tokens(x2, c2["concat"], scale, 32)          # (x * c_in | concat) -> 8 ch, padded to 32
+        return self._run(x_tok, tvec, c2["crossattn"], c2["vector"], batch_size, num_video_frames, H, W, ctrl_frames)
