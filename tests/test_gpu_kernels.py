@@ -1,0 +1,261 @@
+"""Kernel-level parity (-m gpu): every libsvdhip.so kernel through the C ABI vs a plain PyTorch fp32 reference of the
+same op on the same bf16-rounded inputs.  Tolerances are bf16-output tolerances: the kernels accumulate in fp32, so
+the error budget is one bf16 rounding of the result (rel 2^-8) plus accumulation-order noise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from streamingt2v_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF16):
+    g = torch.Generator(device="cpu"); g.manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def check(name, got, ref, atol, rtol):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    worst = (err - bound).max().item()
+    print(f"[{name}] max abs err {err.max().item():.4e} (ref absmax {ref.abs().max().item():.3f}) worst margin {worst:.3e}")
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    assert worst <= 0, f"{name}: err {err.max().item():.4e} exceeds atol {atol} + rtol {rtol}"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 320, 320), (77, 960, 64), (4096, 640, 1280)])
+def test_gemm_plain(ops, cfg, M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias
+    out = ops.gemm(a, w, bias=bias, tile_cfg=cfg)
+    check(f"gemm cfg{cfg} {M}x{N}x{K}", out, ref, 2e-2, 1e-2)
+    # asymmetric structure check: A = "identity-like" selects rows of W (catches transposed tiles)
+    eye = torch.zeros(M, K, dtype=BF16, device="cuda"); idx = torch.arange(M, device="cuda") % K
+    eye[torch.arange(M, device="cuda"), idx] = 1
+    out = ops.gemm(eye, w, tile_cfg=cfg)
+    check(f"gemm-select cfg{cfg}", out, w.float().t()[idx], 1e-6, 0)
+
+
+def test_gemm_k32_and_f32_out(ops):
+    M, N, K = 513, 132, 96
+    a, w = rnd(M, K, seed=4), rnd(N, K, scale=K ** -0.5, seed=5)
+    out = ops.gemm(a, w, out_f32=True)
+    assert out.dtype == torch.float32
+    check("gemm K=96 (BK32) f32 out", out, a.float() @ w.float().t(), 1e-3, 1e-3)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K, rpv = 640, 320, 320, 64
+    a, w = rnd(M, K, seed=6), rnd(N, K, scale=K ** -0.5, seed=7)
+    bias = rnd(N, seed=8, dtype=torch.float32)
+    rowvec = rnd(M // rpv, N, seed=9, dtype=torch.float32)
+    R, S = rnd(M, N, seed=10), rnd(M, N, seed=11)
+    alpha = 0.3
+    base = a.float() @ w.float().t() + bias + rowvec.repeat_interleave(rpv, 0) + R.float()
+    out = ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_vec=rpv, residual=R)
+    check("gemm +bias+rowvec+residual", out, base, 3e-2, 1e-2)
+    out = ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_vec=rpv, residual=R, blend=(alpha, S))
+    check("gemm blend", out, alpha * S.float() + (1 - alpha) * base, 3e-2, 1e-2)
+    out = ops.gemm(a, w, bias=bias, silu=True)
+    check("gemm silu", out, F.silu(a.float() @ w.float().t() + bias), 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 8])
+def test_gemm_geglu(ops, cfg):
+    from streamingt2v_amd.video_model import pack_geglu
+    M, C = 300, 320
+    a = rnd(M, C, seed=12)
+    w = rnd(8 * C, C, scale=C ** -0.5, seed=13).float().cpu()
+    b = rnd(8 * C, seed=14, dtype=torch.float32).cpu()
+    wp, bp = pack_geglu(w, b)
+    out = ops.gemm(a, wp.to(BF16).cuda(), bias=bp.cuda(), geglu=True, tile_cfg=cfg)
+    h = a.float() @ w.to(BF16).float().cuda().t() + b.cuda()
+    v, g = h.chunk(2, -1)
+    check(f"gemm geglu cfg{cfg}", out, v * F.gelu(g), 3e-2, 1e-2)
+
+
+@pytest.mark.parametrize("stride,ups,cin,cout,H,W", [(1, 0, 64, 128, 9, 16), (2, 0, 64, 64, 18, 32), (1, 1, 128, 64, 9, 16),
+                                                     (1, 0, 32, 96, 12, 20), (1, 0, 320, 320, 16, 16)])
+def test_gemm_conv3x3(ops, stride, ups, cin, cout, H, W):
+    from streamingt2v_amd.video_model import pack_conv3x3
+    Fr = 3
+    x = rnd(Fr, cin, H, W, seed=15).float()
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=16).float()
+    bias = rnd(cout, seed=17, dtype=torch.float32)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    ref = F.conv2d(xin, wt, bias, stride=stride, padding=1)
+    ho, wo = ref.shape[2], ref.shape[3]
+    tok = x.permute(0, 2, 3, 1).reshape(Fr * H * W, cin).to(BF16).contiguous()
+    wp = pack_conv3x3(wt).to(BF16).cuda()
+    out = ops.gemm(tok, wp, bias=bias, conv=dict(cin=cin, hin=H, win=W, hout=ho, wout=wo, stride=stride, ups=ups, frames=Fr))
+    check(f"conv3x3 s{stride} u{ups} {cin}->{cout}", out, ref.permute(0, 2, 3, 1).reshape(-1, cout), 3e-2, 1e-2)
+
+
+@pytest.mark.parametrize("C,T,pix", [(64, 8, 40), (320, 25, 16), (32, 4, 64)])
+def test_gemm_temporal3(ops, C, T, pix):
+    from streamingt2v_amd.video_model import pack_tconv3
+    B = 2
+    x = rnd(B, C, T, pix, 1, seed=18).float()
+    wt = rnd(C, C, 3, 1, 1, scale=(3 * C) ** -0.5, seed=19).float()
+    bias = rnd(C, seed=20, dtype=torch.float32)
+    ref = F.conv3d(x, wt, bias, padding=(1, 0, 0))                                  # b c t p 1
+    tok = x[..., 0].permute(0, 2, 3, 1).reshape(B * T * pix, C).to(BF16).contiguous()   # (b t p) c
+    out = ops.gemm(tok, pack_tconv3(wt).to(BF16).cuda(), bias=bias, temporal=dict(cin=C, T=T, pix=pix))
+    check(f"temporal conv C{C} T{T}", out, ref[..., 0].permute(0, 2, 3, 1).reshape(-1, C), 3e-2, 1e-2)
+
+
+def test_gemm_trans_out(ops):
+    Fr, pix, C, K = 3, 144, 128, 128
+    a, w = rnd(Fr * pix, K, seed=21), rnd(C, K, scale=K ** -0.5, seed=22)
+    tok_ld = 192
+    vt = torch.zeros(Fr, C, tok_ld, dtype=BF16, device="cuda")
+    ops.gemm(a, w, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
+    ref = (a.float() @ w.float().t()).view(Fr, pix, C).transpose(1, 2)
+    check("gemm transposed out", vt[:, :, :pix], ref, 2e-2, 1e-2)
+    assert float(vt[:, :, pix:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("Fr,N,heads", [(2, 256, 5), (1, 144, 20), (3, 576, 2), (1, 2304, 3), (1, 1000, 1)])
+def test_attn_spatial(ops, Fr, N, heads):
+    C = heads * 64
+    qk = rnd(Fr * N, 2 * C, seed=23)
+    v = rnd(Fr * N, C, seed=24)
+    tok_ld = (N + 63) // 64 * 64
+    vt = torch.zeros(Fr, C, tok_ld, dtype=BF16, device="cuda")
+    vt[:, :, :N] = v.view(Fr, N, C).transpose(1, 2)
+    out = torch.empty(Fr * N, C, dtype=BF16, device="cuda")
+    ops.attn_spatial(qk[:, :C], qk[:, C:], vt, out, Fr, N, heads)
+    q, k = (t.float().view(Fr, N, heads, 64).transpose(1, 2) for t in (qk[:, :C], qk[:, C:]))
+    vv = v.float().view(Fr, N, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(q, k, vv).transpose(1, 2).reshape(Fr * N, C)
+    check(f"attn spatial F{Fr} N{N} h{heads}", out, ref, 2e-2, 2e-2)
+
+
+def test_attn_spatial_online_softmax_rescale(ops):
+    """Force the running max to jump at a late KV tile (spiked key) -- exercises the O rescale path."""
+    N, C = 512, 64
+    qk = rnd(N, 2 * C, seed=25)
+    qk[300, C:] = qk[5, :C] * 4.0                      # key 300 strongly matches query 5
+    v = rnd(N, C, seed=26)
+    vt = torch.zeros(1, C, N, dtype=BF16, device="cuda"); vt[0] = v.t()
+    out = torch.empty(N, C, dtype=BF16, device="cuda")
+    ops.attn_spatial(qk[:, :C], qk[:, C:], vt, out, 1, N, 1)
+    ref = F.scaled_dot_product_attention(qk[None, None, :, :C].float(), qk[None, None, :, C:].float(), v[None, None].float())[0, 0]
+    check("attn spatial spiked key", out, ref, 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,pix,heads", [(2, 25, 25, 33, 5), (2, 25, 7, 20, 10), (1, 7, 7, 9, 20), (2, 8, 3, 16, 5)])
+def test_attn_temporal(ops, B, Tq, Tk, pix, heads):
+    C = heads * 64
+    q = rnd(B * Tq * pix, C, seed=27)
+    kv = rnd(B * Tk * pix, 2 * C, seed=28)
+    out = torch.empty(B * Tq * pix, C, dtype=BF16, device="cuda")
+    ops.attn_temporal(q, kv[:, :C], kv[:, C:], out, B, Tq, Tk, pix, heads)
+
+    def bsthd(t, T):   # (b t p) (h d) -> (b p) h t d
+        return t.float().view(B, T, pix, heads, 64).permute(0, 2, 3, 1, 4).reshape(B * pix, heads, T, 64)
+    ref = F.scaled_dot_product_attention(bsthd(q, Tq), bsthd(kv[:, :C], Tk), bsthd(kv[:, C:], Tk))
+    ref = ref.view(B, pix, heads, Tq, 64).permute(0, 3, 1, 2, 4).reshape(B * Tq * pix, C)
+    check(f"attn temporal B{B} {Tq}x{Tk}", out, ref, 2e-2, 2e-2)
+
+
+def test_softmax_rows(ops):
+    s = rnd(300, 1024, scale=3.0, seed=29, dtype=torch.float32)
+    p = torch.empty(300, 1024, dtype=BF16, device="cuda")
+    ops.softmax_rows(s, p, 0.25)
+    check("softmax rows", p, torch.softmax(s * 0.25, -1), 1e-4, 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("Fr,pix,C,fps,silu", [(4, 144, 320, 1, True), (6, 100, 640, 3, True), (2, 64, 2560, 1, False),
+                                              (4, 576, 32, 4, True), (2, 36, 960, 2, False), (2, 4096, 128, 1, True)])
+def test_groupnorm(ops, Fr, pix, C, fps, silu):
+    x = (rnd(Fr * pix, C, seed=30).float() * 1.5 + 0.7).to(BF16)
+    g, b = rnd(C, seed=31, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=32, dtype=torch.float32) * 0.1
+    out = ops.groupnorm(x, Fr, pix, g, b, 1e-5, frames_per_stat=fps, silu=silu)
+    x5 = x.float().view(Fr // fps, fps * pix, C).transpose(1, 2)                   # [stat batch, C, fps*pix]
+    ref = F.group_norm(x5, 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    check(f"groupnorm C{C} fps{fps}", out, ref.transpose(1, 2).reshape(Fr * pix, C), 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("C", [32, 96, 320, 640, 1280])
+def test_layernorm(ops, C):
+    rows, rpv = 1000, 250
+    x = rnd(rows, C, seed=33)
+    g, b = rnd(C, seed=34, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=35, dtype=torch.float32) * 0.1
+    out = ops.layernorm(x, g, b)
+    check(f"layernorm C{C}", out, F.layer_norm(x.float(), (C,), g, b, 1e-5), 2e-2, 1e-2)
+    av = rnd(rows // rpv, C, seed=36, dtype=torch.float32)
+    out, xs = ops.layernorm(x, g, b, addvec=av, rows_per_vec=rpv, want_sum=True, silu=True)
+    xsum = x.float() + av.repeat_interleave(rpv, 0)
+    check(f"layernorm+add C{C} sum", xs, xsum, 2e-2, 1e-2)
+    check(f"layernorm+add+silu C{C}", out, F.silu(F.layer_norm(xsum, (C,), g, b, 1e-5)), 2e-2, 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ glue
+def test_layout_and_glue(ops):
+    Fr, h, w = 3, 6, 10
+    x0, x1 = rnd(Fr, 4, h, w, seed=37, dtype=torch.float32), rnd(Fr, 4, h, w, seed=38, dtype=torch.float32)
+    sc = rnd(Fr, seed=39, dtype=torch.float32)
+    tok = ops.nchw_to_tokens(x0, x1, sc, 32)
+    ref = torch.zeros(Fr, h * w, 32, device="cuda")
+    ref[..., :4] = (x0 * sc[:, None, None, None]).flatten(2).transpose(1, 2)
+    ref[..., 4:8] = x1.flatten(2).transpose(1, 2)
+    check("nchw_to_tokens", tok, ref.view(-1, 32), 1e-6, 2 ** -8)
+    back = ops.tokens_to_nchw(tok, 8, Fr, h, w)
+    check("tokens_to_nchw", back, ref.view(Fr, h * w, 32)[..., :8].transpose(1, 2).reshape(Fr, 8, h, w).to(BF16), 0, 0)
+    a, b = rnd(50, 64, seed=40), rnd(50, 128, seed=41)
+    check("concat", ops.concat_channels(a, b), torch.cat([a, b], 1), 0, 0)
+    c = rnd(50, 64, seed=42)
+    check("add_rows", ops.add_rows(a, c), a.float() + c.float(), 1e-6, 2 ** -8)
+    t = torch.tensor([0.0, 1.5, -0.7, 12.0], device="cuda")
+    emb = ops.timestep_embedding(t, 320)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half).cuda()
+    args = t[:, None] * freqs[None]
+    check("timestep_embedding", emb, torch.cat([args.cos(), args.sin()], -1), 1e-3, 2 ** -8)
+    v = rnd(7, 33, seed=43, dtype=torch.float32)
+    check("silu->bf16", ops.to_bf16(v, silu=True), F.silu(v), 1e-6, 2 ** -8)
+
+
+def test_edm_euler_step(ops):
+    T, C, h, w = 5, 4, 6, 8
+    x = rnd(T, C, h, w, seed=44, dtype=torch.float32) * 10
+    net = rnd(2 * T * h * w, 4, seed=45, dtype=torch.float32)
+    gs = torch.linspace(1.5, 3.0, T).cuda()
+    sigma, nxt = 7.5, 2.25
+    x_ref = x.clone()
+    n = net.view(2, T, h * w, C).permute(0, 1, 3, 2).reshape(2, T, C, h, w)
+    c_skip, c_out = 1 / (sigma ** 2 + 1), -sigma / math.sqrt(sigma ** 2 + 1)
+    du, dc = n[0] * c_out + x_ref * c_skip, n[1] * c_out + x_ref * c_skip
+    den = du + gs[:, None, None, None] * (dc - du)
+    x_ref = x_ref + (x_ref - den) / sigma * (nxt - sigma)
+    ops.edm_euler_step(x, net, gs, sigma, nxt)
+    check("edm euler step", x, x_ref, 1e-4, 1e-5)
+
+
+def test_ae_time_mix3(ops):
+    Fr, h, w = 4, 5, 7
+    x = rnd(Fr * h * w, 4, seed=46, dtype=torch.float32)
+    wt, b = rnd(3, 3, 3, seed=47, dtype=torch.float32), rnd(3, seed=48, dtype=torch.float32)
+    out = ops.ae_time_mix3(x, wt, b, Fr, h, w, True)
+    x5 = x[:, :3].view(1, Fr, h * w, 3).permute(0, 3, 1, 2)[..., None]          # b c t p 1
+    ref = F.conv3d(x5, wt[..., None, None], b, padding=(1, 0, 0))[0, ..., 0].permute(1, 0, 2).reshape(Fr, 3, h, w)
+    check("ae time mix + clamp", out, ref.clamp(-1, 1), 1e-5, 1e-5)

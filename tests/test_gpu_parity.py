@@ -1,0 +1,179 @@
+"""Hot-path parity (-m gpu): the HIP execution of the StreamingSVD networks vs the CPU oracle / committed golden
+vectors (reference outputs) on identical seeded weights and inputs.
+
+Tolerance statement.  north_star asks for per-frame L2 <= 1e-3 against the fp32 reference.  The kernels store
+activations in bf16 (8 mantissa bits) with fp32 accumulation, as north_star's "MFMA bf16 tiles" prescribes; one
+bf16 rounding is 2^-9 ~ 2e-3 relative, so a 1e-3 absolute bound on O(1) outputs is not reachable through ~40
+chained bf16 tensors regardless of kernel quality.  What is asserted here:
+  * per-frame RMS error relative to the per-frame RMS of the reference output <= REL_L2 (2e-2),
+  * no systematic error: correlation with the reference >= 0.9995.
+The measured values are printed (and reported in DESIGN.md) so that the gap to 1e-3 is visible, not hidden.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REL_L2 = 2e-2
+
+
+def per_frame_rel_l2(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    e = (got - ref).flatten(1).pow(2).mean(1).sqrt()
+    r = ref.flatten(1).pow(2).mean(1).sqrt()
+    return e, e / r
+
+
+def report(name, got, ref, rel_tol=REL_L2):
+    assert torch.isfinite(got).all(), f"{name}: non-finite"
+    e, rel = per_frame_rel_l2(got, ref)
+    corr = torch.corrcoef(torch.stack([got.float().cpu().flatten(), ref.float().cpu().flatten()]))[0, 1].item()
+    print(f"[{name}] per-frame L2 abs max {e.max():.3e} mean {e.mean():.3e} | rel max {rel.max():.3e} | corr {corr:.6f}")
+    assert rel.max().item() <= rel_tol, f"{name}: per-frame relative L2 {rel.max():.3e} > {rel_tol}"
+    assert corr >= 0.9995, f"{name}: correlation {corr}"
+    return e.max().item(), rel.max().item()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from oracle import cases, svd_oracle as O
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    tu = cases.TINY_UNET
+    cfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"],
+                     channel_mult=tu["channel_mult"], conditioning_embedding_out_channels=tu["cond_embed"])
+    unet, cn = VideoUNet(cfg), ControlNet(cfg)
+    sd_u, sd_c = init_by_name(unet.spec(), seed=1), init_by_name(cn.spec(), seed=2)
+    unet.load_state_dict(sd_u, device="cuda")
+    cn.load_state_dict(sd_c, device="cuda")
+    wrap = StreamingWrapper(unet, cn, tu["Tc"])
+    ocfg = O.Cfg(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"],
+                 channel_mult=tu["channel_mult"], cond_embed_channels=tu["cond_embed"])
+    return dict(unet=unet, cn=cn, wrap=wrap, sd_u=sd_u, sd_c=sd_c, ocfg=ocfg, tu=tu, cases=cases, O=O)
+
+
+def _cuda(d):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def test_video_res_block(tiny):
+    """One VideoResBlock (input_blocks.1.0) in isolation vs oracle."""
+    O, unet, sd = tiny["O"], tiny["unet"], tiny["sd_u"]
+    from streamingt2v_amd import ops
+    T, H, W, Fr = 8, 16, 16, 16
+    g = torch.Generator(); g.manual_seed(5)
+    x = torch.randn(Fr, 320, H, W, generator=g)
+    emb = torch.randn(Fr, 1280, generator=g)
+    blk = unet.input_blocks[1][0]
+    ref = O.video_res_block(sd, "input_blocks.1.0.", x.to(torch.bfloat16).float(), emb, T)
+    tok = x.permute(0, 2, 3, 1).reshape(Fr * H * W, 320).to(torch.bfloat16).cuda().contiguous()
+    out = blk.forward(tok, ops.to_bf16(emb.cuda().contiguous(), silu=True), Fr, T, H, W)
+    out = out.float().view(Fr, H, W, -1).permute(0, 3, 1, 2)
+    report("VideoResBlock", out, ref)
+
+
+def test_spatial_video_transformer(tiny):
+    O, unet, sd = tiny["O"], tiny["unet"], tiny["sd_u"]
+    from streamingt2v_amd import ops
+    T, H, W, Fr = 8, 16, 16, 16
+    g = torch.Generator(); g.manual_seed(6)
+    x = torch.randn(Fr, 320, H, W, generator=g)
+    ctx = torch.randn(Fr, 1, 1024, generator=g)
+    svt = unet.input_blocks[1][1]
+    ref = O.spatial_video_transformer(sd, "input_blocks.1.1.", x.to(torch.bfloat16).float(), ctx, T)
+    tok = x.permute(0, 2, 3, 1).reshape(Fr * H * W, 320).to(torch.bfloat16).cuda().contiguous()
+    c, tc = unet._contexts(ctx.cuda(), T)
+    out = svt.forward(tok, c, tc, Fr, T, H, W).float().view(Fr, H, W, -1).permute(0, 3, 1, 2)
+    report("SpatialVideoTransformer", out, ref)
+
+
+def test_cam_conditional_model(tiny):
+    O, unet, sd = tiny["O"], tiny["unet"], tiny["sd_u"]
+    T, Tc, H, W, B = 8, 3, 16, 16, 2
+    g = torch.Generator(); g.manual_seed(7)
+    s = torch.randn(B * T, 320, H, W, generator=g).to(torch.bfloat16).float()
+    c = torch.randn(B * Tc, 320, H, W, generator=g).to(torch.bfloat16).float()
+    ref = O.conditional_model(sd, "cross_attention_merger_input_blocks.1.", s, c, T, Tc)
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, 320).to(torch.bfloat16).cuda().contiguous()
+    out = unet.cross_attention_merger_input_blocks[1].forward(tok(s), tok(c), B * T, T, Tc, H, W)
+    report("CAM ConditionalModel", out.float().view(B * T, H, W, -1).permute(0, 3, 1, 2), ref)
+
+
+def test_controlnet_cond_embedding(tiny):
+    O, cn, sd = tiny["O"], tiny["cn"], tiny["sd_c"]
+    g = torch.Generator(); g.manual_seed(8)
+    cond = torch.rand(4, 3, 64, 64, generator=g) * 2 - 1
+    ref = O.controlnet_cond_embedding(sd, tiny["ocfg"], cond)
+    out, H, W = cn.controlnet_cond_embedding.forward(cond.cuda())
+    report("ControlNet cond embedding", out.float().view(4, H, W, -1).permute(0, 3, 1, 2), ref)
+
+
+def test_streaming_wrapper_vs_reference_golden(tiny, golden_dir):
+    """StreamingWrapper.forward (ControlNet + UNet + CAM) against the REFERENCE's output (tests/golden)."""
+    gold = torch.load(os.path.join(golden_dir, "wrapper_tiny.pt"))
+    inp = _cuda(tiny["cases"].tiny_wrapper_inputs())
+    tu = tiny["tu"]
+    out = tiny["wrap"].forward(inp["x"], inp["t"], {k: inp[k] for k in ("concat", "crossattn", "vector")},
+                               batch_size=2, num_video_frames=tu["T"],
+                               image_only_indicator=torch.zeros(2, tu["T"], device="cuda"), ctrl_frames=inp["ctrl_frames"])
+    report("StreamingWrapper.forward vs reference", out, gold["out"])
+    # no-ControlNet path (config C2): VideoUNet.forward with hs_control_* = None
+    x = torch.cat((inp["x"], inp["concat"]), 1)
+    out = tiny["unet"].forward(x, inp["t"], context=inp["crossattn"], y=inp["vector"], num_video_frames=tu["T"],
+                               image_only_indicator=torch.zeros(2, tu["T"], device="cuda"))
+    report("VideoUNet.forward (no control) vs reference", out, gold["out_noctrl"])
+
+
+def test_sampler_vs_reference_golden(tiny, golden_dir):
+    """2 Euler-EDM steps (AYS schedule, CFG 1.5->3.0) through the fused sampler vs the reference sampler stack."""
+    from streamingt2v_amd.sampling import EulerEDMSampler
+    gold = torch.load(os.path.join(golden_dir, "sampler_tiny.pt"))
+    tu = tiny["tu"]
+    sin = tiny["cases"].tiny_sampler_inputs()
+    inp = _cuda(tiny["cases"].tiny_wrapper_inputs())
+    sampler = EulerEDMSampler(num_steps=2, num_frames=tu["T"])
+    z = sampler(tiny["wrap"], sin["noise"].cuda().clone(), _cuda(sin["c"]), _cuda(sin["uc"]), batch_size=2,
+                num_video_frames=tu["T"], ctrl_frames=inp["ctrl_frames"])
+    report("EulerEDMSampler 2 steps vs reference", z, gold["z"])
+
+
+def test_vae_decoder_vs_reference_golden(golden_dir):
+    from oracle import cases
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import VaeConfig, VideoDecoder
+    tv = cases.TINY_VAE
+    dec = VideoDecoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]))
+    dec.load_state_dict(init_by_name(dec.spec(), seed=3), device="cuda")
+    gold = torch.load(os.path.join(golden_dir, "vae_tiny.pt"))
+    z = cases.tiny_vae_inputs()["z"].cuda()
+    out = dec.forward(z, timesteps=z.shape[0])
+    report("VideoDecoder vs reference", out, gold["out"])
+
+
+def test_config1_end_to_end_vs_oracle(tiny):
+    """BASELINE config 1 shape of work on the tiny nets: one chunk = sampler steps + temporal VAE decode + clamp,
+    HIP path vs the CPU oracle on identical noise (frames compared before uint8 quantisation)."""
+    O, tu, cases = tiny["O"], tiny["tu"], tiny["cases"]
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.sampling import EulerEDMSampler
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VaeConfig, VideoDecoder
+    tv = cases.TINY_VAE
+    dec = VideoDecoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]))
+    sd_d = init_by_name(dec.spec(), seed=3)
+    dec.load_state_dict(sd_d, device="cuda")
+    T, steps = tu["T"], 4
+    model = StreamingSVD(tiny["wrap"], AutoencodingEngineDecoder(dec), EulerEDMSampler(num_steps=steps, num_frames=T),
+                         num_conditional_frames=tu["Tc"])
+    sin = cases.tiny_sampler_inputs()
+    inp = cases.tiny_wrapper_inputs()
+    frames = model._generate_conditional_output(_cuda(sin["c"]), _cuda(sin["uc"]), inp["ctrl_frames"].cuda(),
+                                                sin["noise"].cuda(), num_steps=steps)
+    net = lambda a, cn_, cc: O.streaming_wrapper(tiny["sd_u"], tiny["sd_c"], tiny["ocfg"], a, cn_, cc, 2, T, tu["Tc"],
+                                                 inp["ctrl_frames"])
+    z = O.euler_edm_sample(net, sin["noise"].clone(), sin["c"], sin["uc"], steps, T)
+    ref = O.decode_first_stage(sd_d, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), z).clamp(-1, 1)
+    assert frames.shape == ref.shape and frames.shape[:2] == (T, 3)
+    report("config-1 chunk (4 steps + decode) vs oracle", frames, ref, rel_tol=5e-2)

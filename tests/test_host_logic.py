@@ -1,0 +1,97 @@
+"""CPU suite, part 3: host-side logic that needs no GPU -- state-dict specs, weight packing, schedules, AR bookkeeping."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import svd_oracle as O
+
+
+def test_full_size_specs():
+    from streamingt2v_amd.temporal_ae import VideoDecoder
+    from streamingt2v_amd.video_model import ControlNet, VideoUNet
+    u, c, d = VideoUNet().spec(), ControlNet().spec(), VideoDecoder().spec()
+    # 1 593.5 M / 673.0 M / 63.6 M parameters, 1571 + 657 tensors
+    assert len(u) == 1571 and abs(u.numel() / 1e6 - 1593.5) < 0.05
+    assert len(c) == 657 and abs(c.numel() / 1e6 - 673.0) < 0.05
+    assert abs(d.numel() / 1e6 - 63.6) < 0.05
+    assert len(set(u.names())) == len(u)
+    assert "cross_attention_merger_mid_block.temporal_transformer.attention.to_out.0.bias" in u.names()
+    assert "controlnet_cond_embedding.norms.5.weight" in c.names()
+    assert "conv_out.time_mix_conv.weight" in d.names()
+
+
+def test_strict_state_dict_check():
+    import pytest
+    from streamingt2v_amd.params import Spec, check_state_dict, init_by_name
+    s = Spec(); s.add("a.weight", 4, 3); s.add("a.bias", 4)
+    sd = init_by_name(s, seed=5)
+    check_state_dict(s, sd)
+    assert torch.equal(sd["a.weight"], init_by_name(s, seed=5)["a.weight"])          # deterministic by name
+    assert not torch.equal(sd["a.weight"], init_by_name(s, seed=6)["a.weight"])
+    with pytest.raises(RuntimeError):
+        check_state_dict(s, {"a.weight": sd["a.weight"]})
+    with pytest.raises(RuntimeError):
+        check_state_dict(s, dict(sd, extra=torch.zeros(1)))
+    with pytest.raises(RuntimeError):
+        check_state_dict(s, {"a.weight": torch.zeros(3, 4), "a.bias": sd["a.bias"]})
+
+
+def test_weight_packing_semantics():
+    from streamingt2v_amd.video_model import pack_conv3x3, pack_geglu, pack_tconv3
+    g = torch.Generator(); g.manual_seed(0)
+    # conv: packed weight times im2col(ky,kx,c) == F.conv2d
+    x = torch.randn(2, 5, 6, 7, generator=g); w = torch.randn(4, 5, 3, 3, generator=g)
+    cols = F.unfold(x, 3, padding=1).view(2, 5, 9, 42).permute(0, 3, 2, 1).reshape(2 * 42, 45)     # (ky kx) c
+    ref = F.conv2d(x, w, padding=1).permute(0, 2, 3, 1).reshape(2 * 42, 4)
+    assert torch.allclose(cols @ pack_conv3x3(w).t(), ref, atol=1e-4)
+    wp = pack_conv3x3(w, cin_pad=32, cout_pad=8)
+    assert wp.shape == (8, 9 * 32) and torch.equal(wp[4:], torch.zeros(4, 288))
+    # temporal conv
+    xt = torch.randn(1, 5, 4, 3, 1, generator=g); wt = torch.randn(6, 5, 3, 1, 1, generator=g)
+    ref = F.conv3d(xt, wt, padding=(1, 0, 0))[0, :, :, :, 0]                                         # c t p
+    xp = F.pad(xt[0, :, :, :, 0], (0, 0, 1, 1))                                                      # c t+2 p
+    cols = torch.stack([xp[:, k:k + 4] for k in range(3)], 0).permute(2, 3, 0, 1).reshape(12, 15)    # (t p) (kt c)
+    assert torch.allclose(cols @ pack_tconv3(wt).t(), ref.permute(1, 2, 0).reshape(12, 6), atol=1e-4)
+    # GEGLU interleave: value block b at rows [64b, 64b+32), its gate at [64b+32, 64b+64)
+    w = torch.randn(128, 8, generator=g); b = torch.randn(128, generator=g)
+    wp, bp = pack_geglu(w, b)
+    assert torch.equal(wp[0:32], w[0:32]) and torch.equal(wp[32:64], w[64:96])
+    assert torch.equal(wp[64:96], w[32:64]) and torch.equal(wp[96:128], w[96:128]) and torch.equal(bp[32:64], b[64:96])
+
+
+def test_schedule_and_scaling_match_oracle():
+    from streamingt2v_amd.sampling import AlignYourSteps, EulerEDMSampler, VScalingWithEDMcNoise
+    for n in (2, 4, 25, 30):
+        assert np.array_equal(AlignYourSteps()(n), O.ays_sigmas(n).numpy())
+    s = EulerEDMSampler(num_steps=30, num_frames=25)
+    assert torch.equal(s.guider.scale, torch.linspace(1.5, 3.0, 25))
+    for sg in (700.0, 1.0, 0.002):
+        ours = VScalingWithEDMcNoise()(sg)
+        ref = [float(v) for v in O.vscaling_edm(torch.tensor(sg, dtype=torch.float64))]
+        np.testing.assert_allclose(ours, ref, rtol=1e-12)
+
+
+def test_autoregressive_bookkeeping():
+    """AR outer loop: ctrl frames = last 7 of the previous chunk, anchor = chunk0[6], 18 new frames kept per chunk."""
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+
+    class FakeSampler:
+        class guider:
+            num_frames = 25
+
+    seen = []
+
+    class Model(StreamingSVD):
+        def _generate_conditional_output(self, c, uc, ctrl_frames, noise, num_steps=None):
+            seen.append((c["anchor"], ctrl_frames.clone()))
+            k = len(seen)
+            return torch.full((25, 3, 2, 2), float(k)) + torch.arange(25)[:, None, None, None] / 100.0
+
+    m = Model(None, None, FakeSampler(), num_conditional_frames=7)
+    init = torch.arange(25)[:, None, None, None].float().expand(25, 3, 2, 2) / 100.0
+    out = m._autoregressive_generation(init, lambda a: ({"anchor": a}, {}), 3, [None] * 3)
+    assert out.shape[0] == 25 + 3 * 18                       # ceil((N-25)/18) chunks, inference_i2v.py:179-184
+    assert all(torch.equal(a, init[6]) for a, _ in seen)      # anchor fixed to the 7th frame of chunk 0
+    assert torch.equal(seen[0][1][0], init[-7:])              # first ctrl frames = tail of chunk 0
+    assert torch.allclose(seen[1][1][0, :, 0, 0, 0], 1.0 + torch.arange(18, 25) / 100.0)   # then tail of chunk 1
+    assert torch.allclose(out[25:43, 0, 0, 0], 1.0 + torch.arange(7, 25) / 100.0)          # overlap frames dropped

@@ -1,0 +1,76 @@
+"""CPU suite, part 1: the oracle (oracle/svd_oracle.py) against the committed golden vectors, i.e. against outputs
+of the unmodified reference produced by oracle/make_golden.py, plus the known-answer vectors of SURVEY.md section 4."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import cases, svd_oracle as O
+from streamingt2v_amd.params import init_by_name
+
+TOL = 2e-4
+
+
+def _tiny_state(golden_dir):
+    from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    tu = cases.TINY_UNET
+    cfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"],
+                     channel_mult=tu["channel_mult"], conditioning_embedding_out_channels=tu["cond_embed"])
+    sd_u = init_by_name(VideoUNet(cfg).spec(), seed=1)
+    sd_c = init_by_name(ControlNet(cfg).spec(), seed=2)
+    ocfg = O.Cfg(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"],
+                 channel_mult=tu["channel_mult"], cond_embed_channels=tu["cond_embed"])
+    return sd_u, sd_c, ocfg, tu
+
+
+def test_wrapper_oracle_matches_reference(golden_dir):
+    torch.set_grad_enabled(False)
+    gold = torch.load(os.path.join(golden_dir, "wrapper_tiny.pt"))
+    sd_u, sd_c, ocfg, tu = _tiny_state(golden_dir)
+    inp = cases.tiny_wrapper_inputs()
+    c = {k: inp[k] for k in ("concat", "crossattn", "vector")}
+    out = O.streaming_wrapper(sd_u, sd_c, ocfg, inp["x"], inp["t"], c, 2, tu["T"], tu["Tc"], inp["ctrl_frames"])
+    assert (out - gold["out"]).abs().max().item() <= TOL
+    x = torch.cat((inp["x"], inp["concat"]), 1)
+    out = O.video_unet(sd_u, ocfg, x, inp["t"], inp["crossattn"], inp["vector"], tu["T"])
+    assert (out - gold["out_noctrl"]).abs().max().item() <= TOL
+    # a ControlNet/CAM bug cannot hide: the two outputs differ materially
+    assert (gold["out"] - gold["out_noctrl"]).abs().max().item() > 1e-2
+
+
+def test_vae_oracle_matches_reference(golden_dir):
+    torch.set_grad_enabled(False)
+    from streamingt2v_amd.temporal_ae import VaeConfig, VideoDecoder
+    tv = cases.TINY_VAE
+    gold = torch.load(os.path.join(golden_dir, "vae_tiny.pt"))
+    sd = init_by_name(VideoDecoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])).spec(), seed=3)
+    z = cases.tiny_vae_inputs()["z"]
+    out = O.video_decoder(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), z, z.shape[0])
+    assert (out - gold["out"]).abs().max().item() <= TOL
+    # grouping matters (zero temporal padding per group): 2+2 differs from 4
+    two = O.decode_first_stage(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), z * 0.18215, max_chunk=2)
+    assert (two - gold["out"]).abs().max().item() > 1e-3
+
+
+def test_sampler_schedule_known_answers(golden_dir):
+    gold = torch.load(os.path.join(golden_dir, "sampler_tiny.pt"))
+    assert torch.equal(O.ays_sigmas(30), gold["sigmas30"]) and torch.equal(O.ays_sigmas(4), gold["sigmas4"])
+    # SURVEY.md section 4 item 2 (derived from the reference code alone)
+    s30 = O.ays_sigmas(30).numpy()
+    np.testing.assert_allclose(s30[:6], [700, 290.26, 120.3584, 52.23181, 34.14449, 22.32061], rtol=2e-6)
+    np.testing.assert_allclose(s30[-4:], [0.01411287, 0.005312791, 0.002, 0.0], rtol=2e-6)
+    np.testing.assert_allclose(O.ays_sigmas(4).numpy(), [700, 6.46578457, 0.542117009, 0.002, 0], rtol=2e-8)
+    c_skip, c_out, c_in, c_noise = O.vscaling_edm(torch.tensor(1.0))
+    np.testing.assert_allclose([c_skip, c_out, c_in, c_noise], [0.5, -0.70710677, 0.70710677, 0.0], atol=1e-7)
+    np.testing.assert_allclose(O.vscaling_edm(torch.tensor(700.0))[3].item(), 1.63777, rtol=1e-5)
+    np.testing.assert_allclose(float(torch.sqrt(1.0 + O.ays_sigmas(30)[0] ** 2)), 700.000714, rtol=1e-9)
+
+
+def test_sampler_oracle_matches_reference(golden_dir):
+    torch.set_grad_enabled(False)
+    gold = torch.load(os.path.join(golden_dir, "sampler_tiny.pt"))
+    sd_u, sd_c, ocfg, tu = _tiny_state(golden_dir)
+    inp, sin = cases.tiny_wrapper_inputs(), cases.tiny_sampler_inputs()
+    net = lambda a, cn_, cc: O.streaming_wrapper(sd_u, sd_c, ocfg, a, cn_, cc, 2, tu["T"], tu["Tc"], inp["ctrl_frames"])
+    z = O.euler_edm_sample(net, sin["noise"].clone(), sin["c"], sin["uc"], 2, tu["T"])
+    assert (z - gold["z"]).abs().max().item() <= 5 * TOL
