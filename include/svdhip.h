@@ -89,6 +89,10 @@ typedef struct svd_gemm_args {
 
 int svd_gemm(const svd_gemm_args* args, svd_stream_t stream);
 int svd_gemm_num_configs(void);
+/* tile config the heuristic would choose for these arguments (1-based), or SVD_EINVAL */
+int svd_gemm_pick_config(const svd_gemm_args* args);
+/* 1 if tile config `cfg` can run these arguments, 0 if not, SVD_EINVAL for an unknown id (used by the autotuner) */
+int svd_gemm_config_valid(const svd_gemm_args* args, int cfg);
 /* fills bm/bn of config id (1-based); returns 0 or SVD_EINVAL */
 int svd_gemm_config_info(int cfg, int* bm, int* bn, int* threads, int* lds_bytes);
 

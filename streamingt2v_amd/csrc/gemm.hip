@@ -308,15 +308,29 @@ __global__ __launch_bounds__(CFG::NT) void gemm_kernel(const svd_gemm_args p) {
 }
 
 // ---- configuration table ---------------------------------------------------------------------------------
-using Cfg1 = GemmCfg<128, 128, 2, 2, 64, true, false>;   // default
-using Cfg2 = GemmCfg<256, 128, 4, 2, 64, true, false>;   // 8 waves, big M
-using Cfg3 = GemmCfg<128, 64, 2, 2, 64, true, false>;    // narrow N (N = 320: 5 tiles)
-using Cfg4 = GemmCfg<128, 320, 2, 2, 64, true, false>;   // N = 320 / 960 exactly, max A reuse
-using Cfg5 = GemmCfg<128, 128, 2, 2, 32, true, false>;   // K / cin multiple of 32 only
-using Cfg6 = GemmCfg<128, 128, 2, 2, 64, false, false>;  // register-staged fallback of Cfg1
-using Cfg7 = GemmCfg<128, 128, 2, 2, 64, true, true>;    // transposed output (V^T for attention)
-using Cfg8 = GemmCfg<256, 256, 4, 2, 64, true, false>;   // 8 waves, 64x128 per wave
-constexpr int kNumCfg = 8;
+//        id  BM   BN   WM WN BK  GLDS   TRANS
+#define SVD_GEMM_CONFIGS(X)                                                                           \
+    X(1, 128, 128, 2, 2, 64, true, false)  /* default: 4 waves, 64x64 per wave, 2 WG/CU            */ \
+    X(2, 256, 128, 4, 2, 64, true, false)  /* 8 waves, 64x64 per wave                              */ \
+    X(3, 128, 64, 2, 2, 64, true, false)   /* narrow N                                             */ \
+    X(4, 128, 320, 2, 2, 64, true, false)  /* N = 320 / 960 exactly, 64x160 per wave               */ \
+    X(5, 128, 128, 2, 2, 32, true, false)  /* K (or cin) multiple of 32 only                       */ \
+    X(6, 128, 128, 2, 2, 64, false, false) /* register-staged fallback of 1                        */ \
+    X(7, 128, 128, 2, 2, 64, true, true)   /* transposed output (V^T for attention)                */ \
+    X(8, 256, 256, 4, 2, 64, true, false)  /* 8 waves, 64x128 per wave                             */ \
+    X(9, 128, 256, 2, 2, 64, true, false)  /* 4 waves, 64x128 per wave                             */ \
+    X(10, 256, 128, 2, 2, 64, true, false) /* 4 waves, 128x64 per wave                             */ \
+    X(11, 256, 256, 2, 2, 64, true, false) /* 4 waves, 128x128 per wave (1 wave / SIMD)            */ \
+    X(12, 64, 128, 2, 2, 64, true, false)  /* small M                                              */ \
+    X(13, 128, 160, 4, 1, 64, true, false) /* N = 320 as 2 tiles, 32x160 per wave                  */ \
+    X(14, 256, 160, 4, 1, 64, true, false) /* N = 320 as 2 tiles, 64x160 per wave                  */ \
+    X(15, 256, 64, 4, 1, 64, true, false)  /* N = 320 as 5 tiles, 64x64 per wave                   */ \
+    X(16, 128, 192, 2, 2, 64, true, false) /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */
+constexpr int kNumCfg = 16;
+
+#define X(id, bm, bn, wm, wn, bk, glds, tr) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr>;
+SVD_GEMM_CONFIGS(X)
+#undef X
 
 template <class CFG, int AMODE>
 int launch_mode(const svd_gemm_args& a, hipStream_t s) {
@@ -347,6 +361,16 @@ void info(int* bm, int* bn, int* thr, int* lds) {
     if (bm) *bm = CFG::BM; if (bn) *bn = CFG::BN; if (thr) *thr = CFG::NT; if (lds) *lds = CFG::LDS_BYTES;
 }
 
+// can config `cfg` run these arguments?  (tile-shape independent checks live in svd_gemm)
+template <class CFG>
+bool cfg_ok(const svd_gemm_args& a) {
+    const int kq = (a.a_mode == SVD_A_PLAIN) ? a.K : a.cin;
+    if (kq % CFG::BK != 0 || a.K % CFG::BK != 0) return false;
+    if (CFG::TRANS != (a.out_mode == SVD_OUT_BF16_T)) return false;
+    if ((a.epi_flags & SVD_EPI_GEGLU) && (CFG::FN % 2 != 0)) return false;   // value|gate frag pairs per wave
+    return true;
+}
+
 int pick_cfg(const svd_gemm_args& a) {
     const int kq = (a.a_mode == SVD_A_PLAIN) ? a.K : a.cin;
     if (a.out_mode == SVD_OUT_BF16_T) return 7;
@@ -361,17 +385,23 @@ int pick_cfg(const svd_gemm_args& a) {
 }  // namespace
 
 extern "C" int svd_gemm_num_configs(void) { return kNumCfg; }
+extern "C" int svd_gemm_pick_config(const svd_gemm_args* args) { return args ? pick_cfg(*args) : SVD_EINVAL; }
 
 extern "C" int svd_gemm_config_info(int cfg, int* bm, int* bn, int* threads, int* lds_bytes) {
     switch (cfg) {
-        case 1: info<Cfg1>(bm, bn, threads, lds_bytes); return SVD_OK;
-        case 2: info<Cfg2>(bm, bn, threads, lds_bytes); return SVD_OK;
-        case 3: info<Cfg3>(bm, bn, threads, lds_bytes); return SVD_OK;
-        case 4: info<Cfg4>(bm, bn, threads, lds_bytes); return SVD_OK;
-        case 5: info<Cfg5>(bm, bn, threads, lds_bytes); return SVD_OK;
-        case 6: info<Cfg6>(bm, bn, threads, lds_bytes); return SVD_OK;
-        case 7: info<Cfg7>(bm, bn, threads, lds_bytes); return SVD_OK;
-        case 8: info<Cfg8>(bm, bn, threads, lds_bytes); return SVD_OK;
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr) case id: info<Cfg##id>(bm, bn, threads, lds_bytes); return SVD_OK;
+        SVD_GEMM_CONFIGS(X)
+#undef X
+    }
+    return SVD_EINVAL;
+}
+
+extern "C" int svd_gemm_config_valid(const svd_gemm_args* args, int cfg) {
+    if (!args) return SVD_EINVAL;
+    switch (cfg) {
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr) case id: return cfg_ok<Cfg##id>(*args) ? 1 : 0;
+        SVD_GEMM_CONFIGS(X)
+#undef X
     }
     return SVD_EINVAL;
 }
@@ -404,22 +434,13 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
     if (a.epi_flags & SVD_EPI_GEGLU) {
         if (a.N % 64 != 0 || a.out_mode != SVD_OUT_BF16) return SVD_EINVAL;
     }
-    int cfg = a.tile_cfg > 0 ? a.tile_cfg : pick_cfg(a);
-    const int kq = (a.a_mode == SVD_A_PLAIN) ? a.K : a.cin;
-    if ((kq % 64 != 0) && cfg != 5) return SVD_EINVAL;
-    if (a.out_mode == SVD_OUT_BF16_T && cfg != 7) return SVD_EINVAL;
-    if (a.out_mode != SVD_OUT_BF16_T && cfg == 7) return SVD_EINVAL;
-    if ((a.epi_flags & SVD_EPI_GEGLU) && (cfg == 3 || cfg == 4)) return SVD_EINVAL;  // need an even frag count per wave
+    const int cfg = a.tile_cfg > 0 ? a.tile_cfg : pick_cfg(a);
+    if (svd_gemm_config_valid(args, cfg) != 1) return SVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     switch (cfg) {
-        case 1: return launch<Cfg1>(a, s);
-        case 2: return launch<Cfg2>(a, s);
-        case 3: return launch<Cfg3>(a, s);
-        case 4: return launch<Cfg4>(a, s);
-        case 5: return launch<Cfg5>(a, s);
-        case 6: return launch<Cfg6>(a, s);
-        case 7: return launch<Cfg7>(a, s);
-        case 8: return launch<Cfg8>(a, s);
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr) case id: return launch<Cfg##id>(a, s);
+        SVD_GEMM_CONFIGS(X)
+#undef X
     }
     return SVD_EINVAL;
 }

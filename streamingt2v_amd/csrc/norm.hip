@@ -56,25 +56,29 @@ __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t 
     }
 }
 
-// one thread per (stat batch, group): reduce frames_per_stat * nchunk partials -> (mean, rstd)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nstat, int groups, int frames_per_stat,
-                                   int nchunk, float count, float eps, float* __restrict__ stats) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nstat * groups) return;
+// one wave per (stat batch, group): reduce frames_per_stat * nchunk partials -> (mean, rstd)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nstat, int groups,
+                                                         int frames_per_stat, int nchunk, float count, float eps,
+                                                         float* __restrict__ stats) {
+    const int i = blockIdx.x;
     const int sb = i / groups, g = i - sb * groups;
+    const int n = frames_per_stat * nchunk;
+    // partial index of entry e (= fr * nchunk + c) : (((sb*fps + fr) * nchunk + c) * groups + g) * 2 = ((sb*n + e) * groups + g) * 2
+    const float* base = partial + ((int64_t)sb * n * groups + g) * 2;
     double a = 0.0, b = 0.0;
-    for (int fr = 0; fr < frames_per_stat; ++fr) {
-        const int f = sb * frames_per_stat + fr;
-        for (int c = 0; c < nchunk; ++c) {
-            const float* p = partial + (((int64_t)f * nchunk + c) * groups + g) * 2;
-            a += p[0]; b += p[1];
-        }
+    for (int e = threadIdx.x; e < n; e += 64) {
+        const float2 v = *(const float2*)(base + (int64_t)e * groups * 2);
+        a += v.x; b += v.y;
     }
-    const double mean = a / count;
-    double var = b / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * i + 0] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (threadIdx.x == 0) {
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * i + 0] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int pix,
@@ -215,7 +219,7 @@ extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frame
     SVD_CHECK_LAUNCH("gn_stats_partial");
     const int nstat = frames / frames_per_stat;
     const float count = (float)frames_per_stat * (float)pix * (float)(channels / groups);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nstat * groups), dim3(64), 0, (hipStream_t)stream, partial,
                        nstat, groups, frames_per_stat, nchunk, count, eps, stats);
     SVD_CHECK_LAUNCH("gn_finalize");
     return SVD_OK;

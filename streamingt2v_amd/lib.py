@@ -14,7 +14,7 @@ ABI_VERSION = 1
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
-    "svd_abi_version", "svd_last_error", "svd_gemm", "svd_gemm_num_configs", "svd_gemm_config_info",
+    "svd_abi_version", "svd_last_error", "svd_gemm", "svd_gemm_num_configs", "svd_gemm_config_info", "svd_gemm_pick_config", "svd_gemm_config_valid",
     "svd_attn_spatial_d64", "svd_attn_temporal_d64", "svd_softmax_rows",
     "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_layernorm",
     "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_silu_f32_to_bf16",
@@ -72,6 +72,8 @@ def _load():
     lib.svd_groupnorm_partial_elems.argtypes = [C.c_int32, C.c_int32]
     i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
     lib.svd_gemm.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.svd_gemm_pick_config.argtypes = [C.POINTER(GemmArgs)]
+    lib.svd_gemm_config_valid.argtypes = [C.POINTER(GemmArgs), C.c_int]
     lib.svd_gemm_config_info.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 4
     lib.svd_attn_spatial_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
     lib.svd_attn_temporal_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]

@@ -16,6 +16,27 @@ BF16 = torch.bfloat16
 
 _zeros = {}
 _gn_ws = {}
+trace = None   # bench.py installs a per-launch HIP-event recorder here (None = zero overhead)
+tuner = None   # tools/tune_gemm.py installs an in-situ tile autotuner here
+
+
+def _load_tile_table():
+    """Measured best tile config per GEMM signature (written by tools/tune_gemm.py on an MI355X).  Signatures that
+    are not in the table use the heuristic of svd_gemm_pick_config."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tiles.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {k: int(v["cfg"]) for k, v in json.load(f)["table"].items()}
+
+
+def gemm_signature(a):
+    return f"m{a.a_mode}_M{a.M}_N{a.N}_K{a.K}_s{a.stride}_u{a.ups}_e{a.epi_flags}_o{a.out_mode}"
+
+
+_tile_table = _load_tile_table()
 
 
 def _stream():
@@ -101,13 +122,28 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
         assert out.shape[0] == M and out.stride(1) == 1
         args.C, args.ldc = out.data_ptr(), out.stride(0)
         args.out_mode = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    if tile_cfg == 0:
+        if tuner is not None:
+            tile_cfg = tuner.select(args, _stream())
+        elif _tile_table:
+            tile_cfg = _tile_table.get(gemm_signature(args), 0)
     args.tile_cfg = tile_cfg
+    if trace is not None:
+        cfg = tile_cfg or _lib.svd_gemm_pick_config(C.byref(args))
+        with trace.launch(f"gemm_cfg{cfg}_mode{args.a_mode}", flops=2.0 * M * N * K):
+            check(_lib.svd_gemm(C.byref(args), _stream()), f"svd_gemm(M={M},N={N},K={K},mode={args.a_mode})")
+        return out
     check(_lib.svd_gemm(C.byref(args), _stream()), f"svd_gemm(M={M},N={N},K={K},mode={args.a_mode})")
     return out
 
 
 def attn_spatial(q, k, vt, out, frames, n_tok, heads):
     """q,k: views into a [frames*n_tok, ld] tensor at the head-0 column; vt: [frames, heads*64, tok_ld]."""
+    if trace is not None:
+        with trace.launch("attn_spatial_d64", flops=4.0 * frames * heads * n_tok * n_tok * 64):
+            check(_lib.svd_attn_spatial_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out),
+                                            out.stride(0), frames, n_tok, heads, _stream()), "svd_attn_spatial_d64")
+        return out
     check(_lib.svd_attn_spatial_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out),
                                     out.stride(0), frames, n_tok, heads, _stream()), "svd_attn_spatial_d64")
     return out

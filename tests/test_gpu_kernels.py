@@ -35,7 +35,7 @@ def check(name, got, ref, atol, rtol):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 320, 320), (77, 960, 64), (4096, 640, 1280)])
 def test_gemm_plain(ops, cfg, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
@@ -74,7 +74,7 @@ def test_gemm_epilogues(ops):
     check("gemm silu", out, F.silu(a.float() @ w.float().t() + bias), 2e-2, 1e-2)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 8])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 9, 10, 11, 12])
 def test_gemm_geglu(ops, cfg):
     from streamingt2v_amd.video_model import pack_geglu
     M, C = 300, 320
