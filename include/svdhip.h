@@ -24,7 +24,11 @@ extern "C" {
 #endif
 
 typedef void* svd_stream_t;      /* hipStream_t */
-typedef uint16_t svd_bf16;       /* raw bfloat16 bits */
+typedef uint16_t svd_bf16;       /* raw 16-bit element (bf16 or fp16 bits, see `dtype`) */
+
+/* element type of every 16-bit tensor of a call: bf16 (default, north_star) or fp16 (the reference's own autocast
+ * precision, config.yaml:8).  Storage 16 bit, accumulation / statistics fp32 in both.  SVD_DTYPE_F32 only where stated. */
+enum { SVD_DTYPE_BF16 = 0, SVD_DTYPE_F16 = 1, SVD_DTYPE_F32 = 2 };
 
 enum {
     SVD_OK = 0,
@@ -85,6 +89,7 @@ typedef struct svd_gemm_args {
     int32_t tok_per_frame; int64_t tokens_ld;  /* SVD_OUT_BF16_T only */
     /* tuning: 0 = heuristic, else explicit tile config id (see svd_gemm_num_configs) */
     int32_t tile_cfg;
+    int32_t dtype;                        /* SVD_DTYPE_BF16 | SVD_DTYPE_F16 : A, W, R, S and 16-bit outputs */
 } svd_gemm_args;
 
 int svd_gemm(const svd_gemm_args* args, svd_stream_t stream);
@@ -107,7 +112,7 @@ int svd_gemm_config_info(int cfg, int* bm, int* bn, int* threads, int* lds_bytes
  */
 int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
                          const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
-                         int32_t frames, int32_t n_tok, int32_t heads, svd_stream_t stream);
+                         int32_t frames, int32_t n_tok, int32_t heads, int32_t dtype, svd_stream_t stream);
 
 /* Per-pixel temporal attention over short sequences (<= 32), head dim 64.
  * Replaces the attention inside VideoTransformerBlock.attn1 (models/svd/sgm/modules/video_attention.py:145-148,
@@ -118,11 +123,11 @@ int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int6
 int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
                           const svd_bf16* V, int64_t ldv, svd_bf16* O, int64_t ldo,
                           int32_t batch, int32_t tq, int32_t tk, int32_t n_pix, int32_t heads,
-                          svd_stream_t stream);
+                          int32_t dtype, svd_stream_t stream);
 
 /* Row softmax: P[r][0..n) = softmax(scale * S[r][0..n)) ; fp32 in, bf16 out (VAE AttnBlock, model.py:180-201). */
 int svd_softmax_rows(const float* S, int64_t lds, svd_bf16* P, int64_t ldp, int64_t rows, int32_t n,
-                     float scale, svd_stream_t stream);
+                     float scale, int32_t dtype, svd_stream_t stream);
 
 /* ---- normalisation --------------------------------------------------------------------------------------
  * GroupNorm(32 groups) on channels-last data, statistics in fp32 over (frames_per_stat frames x pixels x C/G).
@@ -135,10 +140,10 @@ int svd_softmax_rows(const float* S, int64_t lds, svd_bf16* P, int64_t ldp, int6
 int64_t svd_groupnorm_partial_elems(int32_t frames, int32_t channels);
 int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
                         int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats,
-                        svd_stream_t stream);
+                        int32_t dtype, svd_stream_t stream);
 int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
                         int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
-                        const float* gamma, const float* beta, int32_t silu, svd_stream_t stream);
+                        const float* gamma, const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream);
 
 /* LayerNorm over channels per token (eps 1e-5), optional per-frame vector added first (x + vec[frame]) with the
  * sum also written to Xsum (used for "x_mix = x + time_pos_embed" video_attention.py:318-321), optional SiLU
@@ -148,27 +153,27 @@ int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy
 int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
                   const float* gamma, const float* beta, float eps,
                   const float* addvec, int32_t addvec_ld, int32_t rows_per_vec, svd_bf16* Xsum, int64_t ldxsum,
-                  int32_t silu, svd_stream_t stream);
+                  int32_t silu, int32_t dtype, svd_stream_t stream);
 
 /* ---- layout / elementwise glue ---------------------------------------------------------------------------- */
 /* NCHW fp32 (two sources concatenated on C: c0 from X0, c1 from X1, X1 may be NULL) -> channels-last bf16 with
  * channel padding to cpad, scaled per frame by scale[f] (NULL = 1).  (wrappers.py:33 concat + Denoiser c_in) */
 int svd_nchw_to_tokens(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
-                       svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, svd_stream_t stream);
-/* channels-last (bf16 or fp32, first c channels of rows with stride ld) -> NCHW fp32 */
-int svd_tokens_to_nchw(const void* X, int32_t x_is_f32, int64_t ldx, float* Y, int32_t c, int32_t frames,
+                       svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream);
+/* channels-last (x_dtype: BF16 | F16 | F32; first c channels of rows with stride ld) -> NCHW fp32 */
+int svd_tokens_to_nchw(const void* X, int32_t x_dtype, int64_t ldx, float* Y, int32_t c, int32_t frames,
                        int32_t pix, svd_stream_t stream);
 /* Y[m][0..ca) = A[m], Y[m][ca..ca+cb) = B[m]   (th.cat([h, hs.pop()], dim=1), video_model.py:608) */
 int svd_concat_channels(const svd_bf16* A, int64_t lda, int32_t ca, const svd_bf16* B, int64_t ldb, int32_t cb,
                         svd_bf16* Y, int64_t ldy, int64_t rows, svd_stream_t stream);
 /* Y = X + B (row-wise, same shape)  (Merger addition, controlnet.py:41-42) */
 int svd_add_rows(const svd_bf16* X, int64_t ldx, const svd_bf16* B, int64_t ldb, svd_bf16* Y, int64_t ldy,
-                 int64_t rows, int32_t channels, svd_stream_t stream);
-/* y = silu(x) on fp32 vectors (emb_layers' leading SiLU, openaimodel.py:284-290) -> bf16 */
-int svd_silu_f32_to_bf16(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, svd_stream_t stream);
+                 int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream);
+/* fp32 -> 16-bit cast, optionally through SiLU (emb_layers' leading SiLU, openaimodel.py:284-290) */
+int svd_cast_f32(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, int32_t dtype, svd_stream_t stream);
 /* sinusoidal embedding [cos | sin], freqs = exp(-ln(max_period) * i / half)  (util.py:207-231) -> bf16 [n][dim] */
 int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, svd_bf16* Y,
-                           svd_stream_t stream);
+                           int32_t dtype, svd_stream_t stream);
 
 /* ---- sampler glue (Denoiser + LinearPredictionGuider + Euler step) ------------------------------------------
  * One Euler-EDM step tail on the fp32 NCHW state x[T][C][pix]:

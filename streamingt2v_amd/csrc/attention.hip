@@ -3,12 +3,6 @@
 
 namespace {
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
-    bf16x2_t t;
-    t[0] = (__bf16)a; t[1] = (__bf16)b;      // hipcc selects v_cvt_pk_bf16_f32 on gfx950
-    return __builtin_bit_cast(uint32_t, t);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // Spatial self-attention, flash style.  One workgroup = NW waves x 32 query rows; KV tiles of 64 keys.
@@ -20,7 +14,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 //      B-operand fragment of the PV MFMA, matched by one ds_read_b128 of V^T.
 // K and V^T tiles are staged with global_load_lds; swizzle (slot ^= (row>>1)&7) on source address and on read.
 // ------------------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, class E>
 __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ Vt, int64_t tok_ld, svd_bf16* __restrict__ O, int64_t ldo,
@@ -104,8 +98,7 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
             for (int kb = 0; kb < 2; ++kb) {
                 const int row = kb * 32 + l31;
                 const uint4 kf = *(const uint4*)(sK + row * 128 + ((lslot ^ ((row >> 1) & 7)) << 4));
-                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s_acc[kb], 0, 0, 0);
+                s_acc[kb] = E::mfma(kf, qf[ks], s_acc[kb]);
             }
         }
         // mask keys beyond n_tok (last tile only).  register r of block kb, half hi <-> key
@@ -139,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
                 const float p0 = __builtin_amdgcn_exp2f(s_acc[kb][r] * c - m_new);
                 const float p1 = __builtin_amdgcn_exp2f(s_acc[kb][r + 1] * c - m_new);
                 psum += p0 + p1;
-                pk[kb][r >> 1] = cvt_pk_bf16(p0, p1);
+                pk[kb][r >> 1] = E::pack(p0, p1);
             }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -156,8 +149,7 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
             for (int db = 0; db < 2; ++db) {
                 const int row = db * 32 + l31;
                 const uint4 vf = *(const uint4*)(sV + row * 128 + ((lslot ^ ((row >> 1) & 7)) << 4));
-                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf), o_acc[db], 0, 0, 0);
+                o_acc[db] = E::mfma(vf, pf, o_acc[db]);
             }
         }
         svd_wait_dma();
@@ -174,8 +166,8 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 o;
-                o.x = cvt_pk_bf16(o_acc[db][4 * g + 0] * inv, o_acc[db][4 * g + 1] * inv);
-                o.y = cvt_pk_bf16(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv);
+                o.x = E::pack(o_acc[db][4 * g + 0] * inv, o_acc[db][4 * g + 1] * inv);
+                o.y = E::pack(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv);
                 *(uint2*)(Orow + 32 * db + 8 * g + 4 * hi) = o;
             }
     }
@@ -188,6 +180,7 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
 // the problem sit in LDS (bf16) and are read as wave-broadcast 16-byte vectors.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TA_MAXT = 32;
+template <class E>
 __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ V, int64_t ldv, svd_bf16* __restrict__ O, int64_t ldo,
@@ -227,10 +220,10 @@ __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
 #pragma unroll
             for (int d = 0; d < 64; d += 8) {
                 uint4 u = active ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
-                q[d + 0] = bf16lo_to_f32(u.x); q[d + 1] = bf16hi_to_f32(u.x);
-                q[d + 2] = bf16lo_to_f32(u.y); q[d + 3] = bf16hi_to_f32(u.y);
-                q[d + 4] = bf16lo_to_f32(u.z); q[d + 5] = bf16hi_to_f32(u.z);
-                q[d + 6] = bf16lo_to_f32(u.w); q[d + 7] = bf16hi_to_f32(u.w);
+                q[d + 0] = E::lo(u.x); q[d + 1] = E::hi(u.x);
+                q[d + 2] = E::lo(u.y); q[d + 3] = E::hi(u.y);
+                q[d + 4] = E::lo(u.z); q[d + 5] = E::hi(u.z);
+                q[d + 6] = E::lo(u.w); q[d + 7] = E::hi(u.w);
             }
         }
         __syncthreads();
@@ -244,10 +237,10 @@ __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
 #pragma unroll
                 for (int d = 0; d < 64; d += 8) {
                     const uint4 u = *(const uint4*)&sKV[hw][0][j][d];
-                    a0 += q[d + 0] * bf16lo_to_f32(u.x); a1 += q[d + 1] * bf16hi_to_f32(u.x);
-                    a2 += q[d + 2] * bf16lo_to_f32(u.y); a3 += q[d + 3] * bf16hi_to_f32(u.y);
-                    a0 += q[d + 4] * bf16lo_to_f32(u.z); a1 += q[d + 5] * bf16hi_to_f32(u.z);
-                    a2 += q[d + 6] * bf16lo_to_f32(u.w); a3 += q[d + 7] * bf16hi_to_f32(u.w);
+                    a0 += q[d + 0] * E::lo(u.x); a1 += q[d + 1] * E::hi(u.x);
+                    a2 += q[d + 2] * E::lo(u.y); a3 += q[d + 3] * E::hi(u.y);
+                    a0 += q[d + 4] * E::lo(u.z); a1 += q[d + 5] * E::hi(u.z);
+                    a2 += q[d + 6] * E::lo(u.w); a3 += q[d + 7] * E::hi(u.w);
                 }
                 s[j] = ((a0 + a1) + (a2 + a3)) * c;
                 mx = fmaxf(mx, s[j]);
@@ -269,10 +262,10 @@ __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
 #pragma unroll
                 for (int d = 0; d < 64; d += 8) {
                     const uint4 u = *(const uint4*)&sKV[hw][1][j][d];
-                    q[d + 0] += pj * bf16lo_to_f32(u.x); q[d + 1] += pj * bf16hi_to_f32(u.x);
-                    q[d + 2] += pj * bf16lo_to_f32(u.y); q[d + 3] += pj * bf16hi_to_f32(u.y);
-                    q[d + 4] += pj * bf16lo_to_f32(u.z); q[d + 5] += pj * bf16hi_to_f32(u.z);
-                    q[d + 6] += pj * bf16lo_to_f32(u.w); q[d + 7] += pj * bf16hi_to_f32(u.w);
+                    q[d + 0] += pj * E::lo(u.x); q[d + 1] += pj * E::hi(u.x);
+                    q[d + 2] += pj * E::lo(u.y); q[d + 3] += pj * E::hi(u.y);
+                    q[d + 4] += pj * E::lo(u.z); q[d + 5] += pj * E::hi(u.z);
+                    q[d + 6] += pj * E::lo(u.w); q[d + 7] += pj * E::hi(u.w);
                 }
             }
         }
@@ -282,8 +275,8 @@ __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
 #pragma unroll
             for (int d = 0; d < 64; d += 8) {
                 uint4 u;
-                u.x = cvt_pk_bf16(q[d + 0], q[d + 1]); u.y = cvt_pk_bf16(q[d + 2], q[d + 3]);
-                u.z = cvt_pk_bf16(q[d + 4], q[d + 5]); u.w = cvt_pk_bf16(q[d + 6], q[d + 7]);
+                u.x = E::pack(q[d + 0], q[d + 1]); u.y = E::pack(q[d + 2], q[d + 3]);
+                u.z = E::pack(q[d + 4], q[d + 5]); u.w = E::pack(q[d + 6], q[d + 7]);
                 *(uint4*)(op + d) = u;
             }
         }
@@ -291,6 +284,7 @@ __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
 }
 
 // Row softmax, fp32 scores -> bf16 probabilities.  One workgroup per row; row cached in registers (n <= 16384).
+template <class E>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_,
                                                            svd_bf16* __restrict__ P, int64_t ldp, int n, float scale) {
     __shared__ float red[8];
@@ -335,7 +329,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         const int idx = threadIdx.x + i * 256;
         if (idx < nv) {
             uint2 o;
-            o.x = cvt_pk_bf16(v[i].x * inv, v[i].y * inv); o.y = cvt_pk_bf16(v[i].z * inv, v[i].w * inv);
+            o.x = E::pack(v[i].x * inv, v[i].y * inv); o.y = E::pack(v[i].z * inv, v[i].w * inv);
             *(uint2*)(p + idx * 4) = o;
         }
     }
@@ -345,7 +339,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
                                     const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
-                                    int32_t frames, int32_t n_tok, int32_t heads, svd_stream_t stream) {
+                                    int32_t frames, int32_t n_tok, int32_t heads, int32_t dtype, svd_stream_t stream) {
     if (!Q || !K || !Vt || !O || frames <= 0 || n_tok <= 0 || heads <= 0) return SVD_EINVAL;
     if (ldq % 8 || ldk % 8 || tok_ld % 8 || ldo % 4) return SVD_EINVAL;
     if (tok_ld < ((n_tok + 63) / 64) * 64) return SVD_EINVAL;   // V^T rows must cover whole 64-key tiles
@@ -354,8 +348,8 @@ extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf
     const int qblocks = (n_tok + NW * 32 - 1) / (NW * 32);
     const int64_t nwg = (int64_t)frames * heads * qblocks;
     if (nwg > 0x7fffffff) return SVD_EINVAL;
-    hipLaunchKernelGGL(attn_spatial_d64_kernel<NW>, dim3((unsigned)nwg), dim3(NW * 64), 4 * 8192, (hipStream_t)stream,
-                       Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_tok, heads, qblocks);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<NW, E>), dim3((unsigned)nwg), dim3(NW * 64), 4 * 8192,
+                                                 (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_tok, heads, qblocks));
     SVD_CHECK_LAUNCH("attn_spatial_d64");
     return SVD_OK;
 }
@@ -363,7 +357,7 @@ extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf
 extern "C" int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
                                      const svd_bf16* V, int64_t ldv, svd_bf16* O, int64_t ldo,
                                      int32_t batch, int32_t tq, int32_t tk, int32_t n_pix, int32_t heads,
-                                     svd_stream_t stream) {
+                                     int32_t dtype, svd_stream_t stream) {
     if (!Q || !K || !V || !O || batch <= 0 || n_pix <= 0 || heads <= 0) return SVD_EINVAL;
     if (tq <= 0 || tk <= 0 || tq > TA_MAXT || tk > TA_MAXT) return SVD_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return SVD_EINVAL;
@@ -371,18 +365,18 @@ extern "C" int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_b
     const int64_t n_prob = (int64_t)batch * n_pix * heads;
     int64_t blocks = (n_prob + 7) / 8;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(attn_temporal_d64_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(attn_temporal_d64_kernel<E>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                                 Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
     SVD_CHECK_LAUNCH("attn_temporal_d64");
     return SVD_OK;
 }
 
 extern "C" int svd_softmax_rows(const float* S, int64_t lds_, svd_bf16* P, int64_t ldp, int64_t rows, int32_t n,
-                                float scale, svd_stream_t stream) {
+                                float scale, int32_t dtype, svd_stream_t stream) {
     if (!S || !P || rows <= 0 || n <= 0 || n % 4 || n > 16384 || lds_ % 4 || ldp % 4) return SVD_EINVAL;
     if (rows > 0x7fffffff) return SVD_EINVAL;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, lds_, P, ldp, n,
-                       scale);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_rows_kernel<E>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S,
+                                                 lds_, P, ldp, n, scale));
     SVD_CHECK_LAUNCH("softmax_rows");
     return SVD_OK;
 }

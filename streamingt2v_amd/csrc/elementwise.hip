@@ -4,6 +4,7 @@
 namespace {
 
 // NCHW fp32 (X0 | X1 on the channel axis) -> channels-last bf16 rows of cpad channels, scaled per frame.
+template <class E>
 __global__ void nchw_to_tokens_kernel(const float* __restrict__ X0, int c0, const float* __restrict__ X1, int c1,
                                       const float* __restrict__ scale, svd_bf16* __restrict__ Y, int cpad, int frames, int pix) {
     const int64_t total = (int64_t)frames * pix;
@@ -22,20 +23,21 @@ __global__ void nchw_to_tokens_kernel(const float* __restrict__ X0, int c0, cons
                 v[k] = x;
             }
             uint4 w;
-            w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
-            w.z = pack_bf16x2(v[4], v[5]); w.w = pack_bf16x2(v[6], v[7]);
+            w.x = E::pack(v[0], v[1]); w.y = E::pack(v[2], v[3]);
+            w.z = E::pack(v[4], v[5]); w.w = E::pack(v[6], v[7]);
             *(uint4*)(y + cb) = w;
         }
     }
 }
 
+template <class E>
 __global__ void tokens_to_nchw_kernel(const void* __restrict__ X, int is_f32, int64_t ldx, float* __restrict__ Y, int c,
                                       int frames, int pix) {
     const int64_t total = (int64_t)frames * pix;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int f = (int)(i / pix), p = (int)(i - (int64_t)f * pix);
         for (int k = 0; k < c; ++k) {
-            const float v = is_f32 ? ((const float*)X)[i * ldx + k] : bf16_to_f32(((const svd_bf16*)X)[i * ldx + k]);
+            const float v = is_f32 ? ((const float*)X)[i * ldx + k] : E::to_f32(((const svd_bf16*)X)[i * ldx + k]);
             Y[((int64_t)f * c + k) * pix + p] = v;
         }
     }
@@ -53,6 +55,7 @@ __global__ void copy_rows_kernel(const svd_bf16* __restrict__ A, int64_t lda, in
     }
 }
 
+template <class E>
 __global__ void add_rows_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const svd_bf16* __restrict__ B, int64_t ldb,
                                 svd_bf16* __restrict__ Y, int64_t ldy, int64_t rows, int c) {
     const int oct = c >> 3;
@@ -62,21 +65,23 @@ __global__ void add_rows_kernel(const svd_bf16* __restrict__ X, int64_t ldx, con
         const int o = (int)(i - r * oct);
         const uint4 a = *(const uint4*)(X + r * ldx + o * 8), b = *(const uint4*)(B + r * ldb + o * 8);
         uint4 w;
-        w.x = pack_bf16x2(bf16lo_to_f32(a.x) + bf16lo_to_f32(b.x), bf16hi_to_f32(a.x) + bf16hi_to_f32(b.x));
-        w.y = pack_bf16x2(bf16lo_to_f32(a.y) + bf16lo_to_f32(b.y), bf16hi_to_f32(a.y) + bf16hi_to_f32(b.y));
-        w.z = pack_bf16x2(bf16lo_to_f32(a.z) + bf16lo_to_f32(b.z), bf16hi_to_f32(a.z) + bf16hi_to_f32(b.z));
-        w.w = pack_bf16x2(bf16lo_to_f32(a.w) + bf16lo_to_f32(b.w), bf16hi_to_f32(a.w) + bf16hi_to_f32(b.w));
+        w.x = E::pack(E::lo(a.x) + E::lo(b.x), E::hi(a.x) + E::hi(b.x));
+        w.y = E::pack(E::lo(a.y) + E::lo(b.y), E::hi(a.y) + E::hi(b.y));
+        w.z = E::pack(E::lo(a.z) + E::lo(b.z), E::hi(a.z) + E::hi(b.z));
+        w.w = E::pack(E::lo(a.w) + E::lo(b.w), E::hi(a.w) + E::hi(b.w));
         *(uint4*)(Y + r * ldy + o * 8) = w;
     }
 }
 
-__global__ void silu_f32_to_bf16_kernel(const float* __restrict__ X, svd_bf16* __restrict__ Y, int64_t n, int apply) {
+template <class E>
+__global__ void cast_f32_kernel(const float* __restrict__ X, svd_bf16* __restrict__ Y, int64_t n, int apply) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = X[i];
-        Y[i] = f32_to_bf16(apply ? silu_f(x) : x);
+        Y[i] = E::from_f32(apply ? silu_f(x) : x);
     }
 }
 
+template <class E>
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, int dim, float log_max_period,
                                           svd_bf16* __restrict__ Y) {
     const int half = dim >> 1;
@@ -85,8 +90,8 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, in
         const int r = (int)(i / half), k = (int)(i - (int64_t)r * half);
         const float freq = expf(-log_max_period * (float)k / (float)half);
         const float a = t[r] * freq;
-        Y[(int64_t)r * dim + k] = f32_to_bf16(cosf(a));
-        Y[(int64_t)r * dim + half + k] = f32_to_bf16(sinf(a));
+        Y[(int64_t)r * dim + k] = E::from_f32(cosf(a));
+        Y[(int64_t)r * dim + half + k] = E::from_f32(sinf(a));
         if ((dim & 1) && k == 0) Y[(int64_t)r * dim + dim - 1] = 0;
     }
 }
@@ -154,20 +159,22 @@ inline unsigned grid_for(int64_t n, int bs = 256) {
 }  // namespace
 
 extern "C" int svd_nchw_to_tokens(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
-                                  svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, svd_stream_t stream) {
+                                  svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream) {
     if (!X0 || !Y || c0 <= 0 || c1 < 0 || (c1 > 0 && !X1) || cpad % 8 || cpad < c0 + c1 || frames <= 0 || pix <= 0) return SVD_EINVAL;
     if ((uintptr_t)Y & 15) return SVD_EINVAL;
-    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0, (hipStream_t)stream, X0, c0,
-                       X1, c1, scale, Y, cpad, frames, pix);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nchw_to_tokens_kernel<E>, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0,
+                                                 (hipStream_t)stream, X0, c0, X1, c1, scale, Y, cpad, frames, pix));
     SVD_CHECK_LAUNCH("nchw_to_tokens");
     return SVD_OK;
 }
 
-extern "C" int svd_tokens_to_nchw(const void* X, int32_t x_is_f32, int64_t ldx, float* Y, int32_t c, int32_t frames,
+extern "C" int svd_tokens_to_nchw(const void* X, int32_t x_dtype, int64_t ldx, float* Y, int32_t c, int32_t frames,
                                   int32_t pix, svd_stream_t stream) {
     if (!X || !Y || c <= 0 || frames <= 0 || pix <= 0 || ldx < c) return SVD_EINVAL;
-    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0, (hipStream_t)stream, X,
-                       x_is_f32, ldx, Y, c, frames, pix);
+    const int is_f32 = x_dtype == SVD_DTYPE_F32;
+    const int dtype = is_f32 ? SVD_DTYPE_BF16 : x_dtype;
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(tokens_to_nchw_kernel<E>, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0,
+                                                 (hipStream_t)stream, X, is_f32, ldx, Y, c, frames, pix));
     SVD_CHECK_LAUNCH("tokens_to_nchw");
     return SVD_OK;
 }
@@ -184,26 +191,27 @@ extern "C" int svd_concat_channels(const svd_bf16* A, int64_t lda, int32_t ca, c
 }
 
 extern "C" int svd_add_rows(const svd_bf16* X, int64_t ldx, const svd_bf16* B, int64_t ldb, svd_bf16* Y, int64_t ldy,
-                            int64_t rows, int32_t channels, svd_stream_t stream) {
+                            int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream) {
     if (!X || !B || !Y || channels <= 0 || channels % 8 || ldx % 8 || ldb % 8 || ldy % 8 || rows <= 0) return SVD_EINVAL;
     if (((uintptr_t)X | (uintptr_t)B | (uintptr_t)Y) & 15) return SVD_EINVAL;
-    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (channels / 8))), dim3(256), 0, (hipStream_t)stream, X, ldx, B, ldb, Y,
-                       ldy, rows, channels);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_rows_kernel<E>, dim3(grid_for(rows * (channels / 8))), dim3(256), 0,
+                                                 (hipStream_t)stream, X, ldx, B, ldb, Y, ldy, rows, channels));
     SVD_CHECK_LAUNCH("add_rows");
     return SVD_OK;
 }
 
-extern "C" int svd_silu_f32_to_bf16(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, svd_stream_t stream) {
+extern "C" int svd_cast_f32(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, int32_t dtype, svd_stream_t stream) {
     if (!X || !Y || n <= 0) return SVD_EINVAL;
-    hipLaunchKernelGGL(silu_f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, X, Y, n, apply_silu);
-    SVD_CHECK_LAUNCH("silu_f32_to_bf16");
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(cast_f32_kernel<E>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, X, Y, n, apply_silu));
+    SVD_CHECK_LAUNCH("cast_f32");
     return SVD_OK;
 }
 
-extern "C" int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, svd_bf16* Y, svd_stream_t stream) {
+extern "C" int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, svd_bf16* Y, int32_t dtype,
+                                      svd_stream_t stream) {
     if (!t || !Y || n <= 0 || dim < 2) return SVD_EINVAL;
-    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((int64_t)n * (dim / 2))), dim3(256), 0, (hipStream_t)stream, t, n,
-                       dim, logf(max_period), Y);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(timestep_embedding_kernel<E>, dim3(grid_for((int64_t)n * (dim / 2))), dim3(256), 0,
+                                                 (hipStream_t)stream, t, n, dim, logf(max_period), Y));
     SVD_CHECK_LAUNCH("timestep_embedding");
     return SVD_OK;
 }

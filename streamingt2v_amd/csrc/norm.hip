@@ -16,6 +16,7 @@ __host__ __device__ inline int gn_nchunk(int frames, int pix) {
 
 // blockDim = octets * R ; thread -> fixed channel octet (8 channels), rows strided by R.
 // partial[f][chunk][g][2] = (sum, sumsq) over the chunk's pixels of group g.
+template <class E>
 __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t ldx, int pix, int channels, int groups,
                                         int nchunk, float* __restrict__ partial) {
     extern __shared__ float sch[];   // [channels][2]
@@ -35,8 +36,8 @@ __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t 
         const svd_bf16* base = X + ((int64_t)f * pix) * ldx + o * 8;
         for (int r = r0 + rr; r < r1; r += R) {
             const uint4 u = *(const uint4*)(base + (int64_t)r * ldx);
-            float v[8] = {bf16lo_to_f32(u.x), bf16hi_to_f32(u.x), bf16lo_to_f32(u.y), bf16hi_to_f32(u.y),
-                          bf16lo_to_f32(u.z), bf16hi_to_f32(u.z), bf16lo_to_f32(u.w), bf16hi_to_f32(u.w)};
+            float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y),
+                          E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
 #pragma unroll
             for (int i = 0; i < 8; ++i) { s[i] += v[i]; ss[i] += v[i] * v[i]; }
         }
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+template <class E>
 __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int pix,
                                 int channels, int groups, int frames_per_stat, int nchunk, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int silu) {
@@ -107,22 +109,22 @@ __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd
     svd_bf16* yb = Y + ((int64_t)f * pix) * ldy + o * 8;
     for (int r = r0 + rr; r < r1; r += R) {
         const uint4 u = *(const uint4*)(xb + (int64_t)r * ldx);
-        float v[8] = {bf16lo_to_f32(u.x), bf16hi_to_f32(u.x), bf16lo_to_f32(u.y), bf16hi_to_f32(u.y),
-                      bf16lo_to_f32(u.z), bf16hi_to_f32(u.z), bf16lo_to_f32(u.w), bf16hi_to_f32(u.w)};
+        float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y),
+                      E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             v[i] = v[i] * ca[i] + cb[i];
             if (silu) v[i] = silu_f(v[i]);
         }
         uint4 w;
-        w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
-        w.z = pack_bf16x2(v[4], v[5]); w.w = pack_bf16x2(v[6], v[7]);
+        w.x = E::pack(v[0], v[1]); w.y = E::pack(v[2], v[3]);
+        w.z = E::pack(v[4], v[5]); w.w = E::pack(v[6], v[7]);
         *(uint4*)(yb + (int64_t)r * ldy) = w;
     }
 }
 
 // LayerNorm: one wave per token row; up to MAXV 16-byte vectors per lane (C <= 64*8*MAXV).
-template <int MAXV>
+template <int MAXV, class E>
 __global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y,
                                                         int64_t ldy, int64_t rows, int channels, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
@@ -141,16 +143,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restri
             const int o = lane + 64 * k;
             if (o < octets) {
                 const uint4 u = *(const uint4*)(xr + o * 8);
-                v[k][0] = bf16lo_to_f32(u.x); v[k][1] = bf16hi_to_f32(u.x); v[k][2] = bf16lo_to_f32(u.y); v[k][3] = bf16hi_to_f32(u.y);
-                v[k][4] = bf16lo_to_f32(u.z); v[k][5] = bf16hi_to_f32(u.z); v[k][6] = bf16lo_to_f32(u.w); v[k][7] = bf16hi_to_f32(u.w);
+                v[k][0] = E::lo(u.x); v[k][1] = E::hi(u.x); v[k][2] = E::lo(u.y); v[k][3] = E::hi(u.y);
+                v[k][4] = E::lo(u.z); v[k][5] = E::hi(u.z); v[k][6] = E::lo(u.w); v[k][7] = E::hi(u.w);
                 if (av) {
                     const float4 a0 = *(const float4*)(av + o * 8), a1 = *(const float4*)(av + o * 8 + 4);
                     v[k][0] += a0.x; v[k][1] += a0.y; v[k][2] += a0.z; v[k][3] += a0.w;
                     v[k][4] += a1.x; v[k][5] += a1.y; v[k][6] += a1.z; v[k][7] += a1.w;
                     if (Xsum) {
                         uint4 w;
-                        w.x = pack_bf16x2(v[k][0], v[k][1]); w.y = pack_bf16x2(v[k][2], v[k][3]);
-                        w.z = pack_bf16x2(v[k][4], v[k][5]); w.w = pack_bf16x2(v[k][6], v[k][7]);
+                        w.x = E::pack(v[k][0], v[k][1]); w.y = E::pack(v[k][2], v[k][3]);
+                        w.z = E::pack(v[k][4], v[k][5]); w.w = E::pack(v[k][6], v[k][7]);
                         *(uint4*)(Xsum + row * ldxsum + o * 8) = w;
                     }
                 }
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restri
                     if (silu) y[i] = silu_f(y[i]);
                 }
                 uint4 w;
-                w.x = pack_bf16x2(y[0], y[1]); w.y = pack_bf16x2(y[2], y[3]);
-                w.z = pack_bf16x2(y[4], y[5]); w.w = pack_bf16x2(y[6], y[7]);
+                w.x = E::pack(y[0], y[1]); w.y = E::pack(y[2], y[3]);
+                w.z = E::pack(y[4], y[5]); w.w = E::pack(y[6], y[7]);
                 *(uint4*)(Y + row * ldy + o * 8) = w;
             }
         }
@@ -207,15 +209,15 @@ extern "C" int64_t svd_groupnorm_partial_elems(int32_t frames, int32_t channels)
 
 extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
                                    int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats,
-                                   svd_stream_t stream) {
+                                   int32_t dtype, svd_stream_t stream) {
     if (!X || !partial || !stats || frames <= 0 || pix <= 0 || channels <= 0) return SVD_EINVAL;
     if (groups <= 0 || groups > 32 || channels % groups || channels % 8 || ldx % 8 || channels > 8192) return SVD_EINVAL;
     if (frames_per_stat <= 0 || frames % frames_per_stat || frames > 65535) return SVD_EINVAL;
     if ((uintptr_t)X & 15) return SVD_EINVAL;
     const int nchunk = gn_nchunk(frames, pix);
     const int bs = gn_block(channels);
-    hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, frames), dim3(bs), 2 * channels * sizeof(float),
-                       (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_stats_partial_kernel<E>, dim3(nchunk, frames), dim3(bs), 2 * channels * sizeof(float),
+                                                 (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
     SVD_CHECK_LAUNCH("gn_stats_partial");
     const int nstat = frames / frames_per_stat;
     const float count = (float)frames_per_stat * (float)pix * (float)(channels / groups);
@@ -227,22 +229,22 @@ extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frame
 
 extern "C" int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
                                    int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
-                                   const float* gamma, const float* beta, int32_t silu, svd_stream_t stream) {
+                                   const float* gamma, const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream) {
     if (!X || !Y || !stats || !gamma || !beta || frames <= 0 || pix <= 0) return SVD_EINVAL;
     if (groups <= 0 || groups > 32 || channels % groups || channels % 8 || ldx % 8 || ldy % 8 || channels > 8192) return SVD_EINVAL;
     if (frames_per_stat <= 0 || frames % frames_per_stat || frames > 65535) return SVD_EINVAL;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return SVD_EINVAL;
     const int nchunk = gn_nchunk(frames, pix);
     const int bs = gn_block(channels);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy, pix,
-                       channels, groups, frames_per_stat, nchunk, stats, gamma, beta, silu);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_apply_kernel<E>, dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy,
+                                                 pix, channels, groups, frames_per_stat, nchunk, stats, gamma, beta, silu));
     SVD_CHECK_LAUNCH("gn_apply");
     return SVD_OK;
 }
 
 extern "C" int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
                              const float* gamma, const float* beta, float eps, const float* addvec, int32_t addvec_ld,
-                             int32_t rows_per_vec, svd_bf16* Xsum, int64_t ldxsum, int32_t silu, svd_stream_t stream) {
+                             int32_t rows_per_vec, svd_bf16* Xsum, int64_t ldxsum, int32_t silu, int32_t dtype, svd_stream_t stream) {
     if (!X || !Y || !gamma || !beta || rows <= 0 || channels <= 0 || channels % 8 || ldx % 8 || ldy % 8) return SVD_EINVAL;
     if (channels > 64 * 8 * 4) return SVD_EINVAL;
     if (addvec && (rows_per_vec <= 0 || addvec_ld % 4)) return SVD_EINVAL;
@@ -251,9 +253,10 @@ extern "C" int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     const int octets = channels / 8;
-#define LN_LAUNCH(MV)                                                                                              \
-    hipLaunchKernelGGL(layernorm_kernel<MV>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, \
-                       rows, channels, gamma, beta, eps, addvec, addvec_ld, rows_per_vec, Xsum, ldxsum, silu)
+#define LN_LAUNCH(MV)                                                                                                        \
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_kernel<MV, E>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
+                                                 X, ldx, Y, ldy, rows, channels, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,    \
+                                                 Xsum, ldxsum, silu))
     if (octets <= 64) LN_LAUNCH(1);
     else if (octets <= 128) LN_LAUNCH(2);
     else if (octets <= 192) LN_LAUNCH(3);

@@ -5,24 +5,14 @@
 #include "../../include/svdhip.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 #define SVD_WAVE 64
 
-__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ float bf16lo_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
-__device__ __forceinline__ float bf16hi_to_f32(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -36,6 +26,45 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- 16-bit element types ------------------------------------------------------------------------------------
+// Every kernel is templated on one of these: storage is 16 bit, arithmetic fp32.  bf16 is the default (north_star);
+// fp16 is what the reference's own autocast uses (config.yaml:8 "16-mixed") and has 8x finer rounding at the same
+// MFMA rate.  lo/hi: the two elements of a packed dword; pack: round-to-nearest-even.
+struct ElemBF16 {
+    static constexpr int kId = SVD_DTYPE_BF16;
+    static __device__ __forceinline__ float lo(uint32_t v) { return __uint_as_float(v << 16); }
+    static __device__ __forceinline__ float hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        bf16x2_t t; t[0] = (__bf16)a; t[1] = (__bf16)b;            // v_cvt_pk_bf16_f32 on gfx950
+        return __builtin_bit_cast(uint32_t, t);
+    }
+    static __device__ __forceinline__ uint16_t from_f32(float a) { return __builtin_bit_cast(uint16_t, (__bf16)a); }
+    static __device__ __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+struct ElemF16 {
+    static constexpr int kId = SVD_DTYPE_F16;
+    static __device__ __forceinline__ float lo(uint32_t v) { return (float)__builtin_bit_cast(f16x2_t, v)[0]; }
+    static __device__ __forceinline__ float hi(uint32_t v) { return (float)__builtin_bit_cast(f16x2_t, v)[1]; }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        f16x2_t t; t[0] = (_Float16)a; t[1] = (_Float16)b;
+        return __builtin_bit_cast(uint32_t, t);
+    }
+    static __device__ __forceinline__ uint16_t from_f32(float a) { return __builtin_bit_cast(uint16_t, (_Float16)a); }
+    static __device__ __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+#define SVD_DISPATCH_DTYPE(dtype, ...)                                     \
+    do {                                                                   \
+        if ((dtype) == SVD_DTYPE_BF16) { using E = ElemBF16; __VA_ARGS__; } \
+        else if ((dtype) == SVD_DTYPE_F16) { using E = ElemF16; __VA_ARGS__; } \
+        else return SVD_EINVAL;                                            \
+    } while (0)
 
 // LDS-DMA (global -> LDS, 16 B per lane, lane-linear destination) issued from inline asm so that hipcc does NOT
 // count it: with the builtin form the compiler drains vmcnt(0) before the next ds_read of ANY LDS address, which

@@ -10,14 +10,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvdhip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
     "svd_abi_version", "svd_last_error", "svd_gemm", "svd_gemm_num_configs", "svd_gemm_config_info", "svd_gemm_pick_config", "svd_gemm_config_valid",
     "svd_attn_spatial_d64", "svd_attn_temporal_d64", "svd_softmax_rows",
     "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_layernorm",
-    "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_silu_f32_to_bf16",
+    "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32",
     "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
 ]
 
@@ -25,6 +25,7 @@ A_PLAIN, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
 OUT_BF16, OUT_F32, OUT_BF16_T = 0, 1, 2
 EPI_GEGLU = 1
 EPI_SILU = 2
+DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
 
 class GemmArgs(C.Structure):
@@ -50,6 +51,7 @@ class GemmArgs(C.Structure):
         ("out_mode", C.c_int32),
         ("tok_per_frame", C.c_int32), ("tokens_ld", C.c_int64),
         ("tile_cfg", C.c_int32),
+        ("dtype", C.c_int32),
     ]
 
 
@@ -75,18 +77,18 @@ def _load():
     lib.svd_gemm_pick_config.argtypes = [C.POINTER(GemmArgs)]
     lib.svd_gemm_config_valid.argtypes = [C.POINTER(GemmArgs), C.c_int]
     lib.svd_gemm_config_info.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 4
-    lib.svd_attn_spatial_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
-    lib.svd_attn_temporal_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]
-    lib.svd_softmax_rows.argtypes = [vp, i64, vp, i64, i64, i32, f32, vp]
-    lib.svd_groupnorm_stats.argtypes = [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp]
-    lib.svd_groupnorm_apply.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
-    lib.svd_layernorm.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, f32, vp, i32, i32, vp, i64, i32, vp]
-    lib.svd_nchw_to_tokens.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]
+    lib.svd_attn_spatial_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
+    lib.svd_attn_temporal_d64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp]
+    lib.svd_softmax_rows.argtypes = [vp, i64, vp, i64, i64, i32, f32, i32, vp]
+    lib.svd_groupnorm_stats.argtypes = [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]
+    lib.svd_groupnorm_apply.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp]
+    lib.svd_layernorm.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, f32, vp, i32, i32, vp, i64, i32, i32, vp]
+    lib.svd_nchw_to_tokens.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.svd_tokens_to_nchw.argtypes = [vp, i32, i64, vp, i32, i32, i32, vp]
     lib.svd_concat_channels.argtypes = [vp, i64, i32, vp, i64, i32, vp, i64, i64, vp]
-    lib.svd_add_rows.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
-    lib.svd_silu_f32_to_bf16.argtypes = [vp, vp, i64, i32, vp]
-    lib.svd_timestep_embedding.argtypes = [vp, i32, i32, f32, vp, vp]
+    lib.svd_add_rows.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
+    lib.svd_cast_f32.argtypes = [vp, vp, i64, i32, i32, vp]
+    lib.svd_timestep_embedding.argtypes = [vp, i32, i32, f32, vp, i32, vp]
     lib.svd_edm_euler_step.argtypes = [vp, vp, i64, vp, i32, i32, i32, f32, f32, vp]
     lib.svd_ae_time_mix3.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, vp]
     for s in SYMBOLS:

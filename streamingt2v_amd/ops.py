@@ -13,6 +13,22 @@ from .lib import A_CONV3X3, A_PLAIN, A_TEMPORAL3, EPI_GEGLU, EPI_SILU, OUT_BF16,
 
 _lib = _l.lib
 BF16 = torch.bfloat16
+F16 = torch.float16
+_DT = {torch.bfloat16: _l.DTYPE_BF16, torch.float16: _l.DTYPE_F16, torch.float32: _l.DTYPE_F32}
+
+# Element type new 16-bit tensors are created in when no 16-bit input exists to inherit it from (casts of fp32 inputs,
+# packed weights).  bf16 is the default; set_element_dtype(torch.float16) selects the reference's autocast precision.
+ELEM = torch.bfloat16
+
+
+def set_element_dtype(dt):
+    global ELEM
+    assert dt in (torch.bfloat16, torch.float16)
+    ELEM = dt
+
+
+def _dt(t):
+    return _DT[t.dtype]
 
 _zeros = {}
 _gn_ws = {}
@@ -33,6 +49,7 @@ def _load_tile_table():
 
 
 def gemm_signature(a):
+    # the tile choice does not depend on the element type (bf16 and fp16 MFMA have the same shape and rate)
     return f"m{a.a_mode}_M{a.M}_N{a.N}_K{a.K}_s{a.stride}_u{a.ups}_e{a.epi_flags}_o{a.out_mode}"
 
 
@@ -50,7 +67,7 @@ def _p(t):
 def zeros_page(device):
     z = _zeros.get(device)
     if z is None:
-        z = torch.zeros(256, dtype=BF16, device=device)
+        z = torch.zeros(256, dtype=torch.int16, device=device)   # all-zero bits are 0.0 in bf16 and fp16
         _zeros[device] = z
     return z
 
@@ -68,7 +85,8 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
     w: [N, K] bf16.   conv = dict(cin, hin, win, hout, wout, stride, ups, frames)   temporal = dict(cin, T, pix, M)
     blend = (alpha: float, S tensor).   trans_out = dict(tok_per_frame, tokens_ld, out=tensor [frames, N, tokens_ld])
     """
-    assert a.dtype == BF16 and w.dtype == BF16 and a.is_cuda and w.is_cuda
+    assert a.dtype in (BF16, F16) and w.dtype == a.dtype and a.is_cuda and w.is_cuda
+    edt = a.dtype
     N, K = w.shape[0], (k if k is not None else w.shape[1])
     args = GemmArgs()
     args.A, args.lda = a.data_ptr(), a.stride(0)
@@ -96,11 +114,11 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
         assert rowvec.dtype == torch.float32 and rowvec.stride(-1) == 1
         args.rowvec, args.rowvec_ld, args.rows_per_vec = rowvec.data_ptr(), rowvec.stride(0), rows_per_vec
     if residual is not None:
-        assert residual.dtype == BF16
+        assert residual.dtype == edt
         args.R, args.ldr = residual.data_ptr(), residual.stride(0)
     if blend is not None:
         alpha, S = blend
-        assert S.dtype == BF16
+        assert S.dtype == edt
         args.S, args.lds, args.alpha = S.data_ptr(), S.stride(0), float(alpha)
     nout = N // 2 if geglu else N
     if n_out is not None:
@@ -111,17 +129,19 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
         args.epi_flags |= EPI_SILU
     if trans_out is not None:
         o = trans_out["out"]
-        assert o.dtype == BF16
+        assert o.dtype == edt
         args.C, args.ldc = o.data_ptr(), 0
         args.out_mode = OUT_BF16_T
         args.tok_per_frame, args.tokens_ld = trans_out["tok_per_frame"], trans_out["tokens_ld"]
         out = o
     else:
         if out is None:
-            out = torch.empty((M, nout), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+            out = torch.empty((M, nout), dtype=torch.float32 if out_f32 else edt, device=a.device)
         assert out.shape[0] == M and out.stride(1) == 1
         args.C, args.ldc = out.data_ptr(), out.stride(0)
         args.out_mode = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+        assert out.dtype in (torch.float32, edt)
+    args.dtype = _DT[edt]
     if tile_cfg == 0:
         if tuner is not None:
             tile_cfg = tuner.select(args, _stream())
@@ -142,22 +162,22 @@ def attn_spatial(q, k, vt, out, frames, n_tok, heads):
     if trace is not None:
         with trace.launch("attn_spatial_d64", flops=4.0 * frames * heads * n_tok * n_tok * 64):
             check(_lib.svd_attn_spatial_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out),
-                                            out.stride(0), frames, n_tok, heads, _stream()), "svd_attn_spatial_d64")
+                                            out.stride(0), frames, n_tok, heads, _dt(q), _stream()), "svd_attn_spatial_d64")
         return out
     check(_lib.svd_attn_spatial_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out),
-                                    out.stride(0), frames, n_tok, heads, _stream()), "svd_attn_spatial_d64")
+                                    out.stride(0), frames, n_tok, heads, _dt(q), _stream()), "svd_attn_spatial_d64")
     return out
 
 
 def attn_temporal(q, k, v, out, batch, tq, tk, n_pix, heads):
     check(_lib.svd_attn_temporal_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
-                                     out.stride(0), batch, tq, tk, n_pix, heads, _stream()), "svd_attn_temporal_d64")
+                                     out.stride(0), batch, tq, tk, n_pix, heads, _dt(q), _stream()), "svd_attn_temporal_d64")
     return out
 
 
 def softmax_rows(s, out, scale):
     rows, n = s.shape
-    check(_lib.svd_softmax_rows(_p(s), s.stride(0), _p(out), out.stride(0), rows, n, float(scale), _stream()),
+    check(_lib.svd_softmax_rows(_p(s), s.stride(0), _p(out), out.stride(0), rows, n, float(scale), _dt(out), _stream()),
           "svd_softmax_rows")
     return out
 
@@ -180,11 +200,11 @@ def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False
     assert rows == frames * pix
     partial, stats = _gn_workspace(x.device, frames, Cc)
     check(_lib.svd_groupnorm_stats(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, float(eps), _p(partial),
-                                   _p(stats), _stream()), "svd_groupnorm_stats")
+                                   _p(stats), _dt(x), _stream()), "svd_groupnorm_stats")
     if out is None:
-        out = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
     check(_lib.svd_groupnorm_apply(_p(x), ld, _p(out), out.stride(0), frames, pix, Cc, groups, frames_per_stat,
-                                   _p(stats), _p(gamma), _p(beta), int(silu), _stream()), "svd_groupnorm_apply")
+                                   _p(stats), _p(gamma), _p(beta), int(silu), _dt(x), _stream()), "svd_groupnorm_apply")
     return out
 
 
@@ -192,11 +212,11 @@ def layernorm(x, gamma, beta, *, eps=1e-5, addvec=None, rows_per_vec=0, want_sum
     rows, ld = _rows_ld(x)
     Cc = x.shape[1]
     if out is None:
-        out = torch.empty((rows, Cc), dtype=BF16, device=x.device)
-    xsum = torch.empty((rows, Cc), dtype=BF16, device=x.device) if want_sum else None
+        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    xsum = torch.empty((rows, Cc), dtype=x.dtype, device=x.device) if want_sum else None
     check(_lib.svd_layernorm(_p(x), ld, _p(out), out.stride(0), rows, Cc, _p(gamma), _p(beta), float(eps),
                              _p(addvec), addvec.stride(0) if addvec is not None else 0, rows_per_vec,
-                             _p(xsum), xsum.stride(0) if xsum is not None else 0, int(silu), _stream()),
+                             _p(xsum), xsum.stride(0) if xsum is not None else 0, int(silu), _dt(x), _stream()),
           "svd_layernorm")
     return (out, xsum) if want_sum else out
 
@@ -209,22 +229,22 @@ def nchw_to_tokens(x0, x1, scale, cpad):
     assert x0.dtype == torch.float32 and x0.is_contiguous()
     if x1 is not None:
         assert x1.dtype == torch.float32 and x1.is_contiguous() and x1.shape[0] == F_
-    out = torch.empty((F_ * pix, cpad), dtype=BF16, device=x0.device)
-    check(_lib.svd_nchw_to_tokens(_p(x0), c0, _p(x1), c1, _p(scale), _p(out), cpad, F_, pix, _stream()),
+    out = torch.empty((F_ * pix, cpad), dtype=ELEM, device=x0.device)
+    check(_lib.svd_nchw_to_tokens(_p(x0), c0, _p(x1), c1, _p(scale), _p(out), cpad, F_, pix, _dt(out), _stream()),
           "svd_nchw_to_tokens")
     return out
 
 
 def tokens_to_nchw(x, c, frames, h, w):
     out = torch.empty((frames, c, h, w), dtype=torch.float32, device=x.device)
-    check(_lib.svd_tokens_to_nchw(_p(x), int(x.dtype == torch.float32), x.stride(0), _p(out), c, frames, h * w,
+    check(_lib.svd_tokens_to_nchw(_p(x), _dt(x), x.stride(0), _p(out), c, frames, h * w,
                                   _stream()), "svd_tokens_to_nchw")
     return out
 
 
 def concat_channels(a, b):
     rows = a.shape[0]
-    out = torch.empty((rows, a.shape[1] + b.shape[1]), dtype=BF16, device=a.device)
+    out = torch.empty((rows, a.shape[1] + b.shape[1]), dtype=a.dtype, device=a.device)
     check(_lib.svd_concat_channels(_p(a), a.stride(0), a.shape[1], _p(b), b.stride(0), b.shape[1], _p(out),
                                    out.stride(0), rows, _stream()), "svd_concat_channels")
     return out
@@ -233,22 +253,25 @@ def concat_channels(a, b):
 def add_rows(x, b):
     out = torch.empty_like(x)
     check(_lib.svd_add_rows(_p(x), x.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1],
-                            _stream()), "svd_add_rows")
+                            _dt(x), _stream()), "svd_add_rows")
     return out
 
 
-def to_bf16(x, silu=False):
-    """fp32 -> bf16 (optionally through SiLU) -- the only 'cast' kernel; x any shape, contiguous."""
+def to_elem(x, silu=False):
+    """fp32 -> ELEM (optionally through SiLU) -- the only 'cast' kernel; x any shape, contiguous."""
     assert x.dtype == torch.float32 and x.is_contiguous()
-    out = torch.empty(x.shape, dtype=BF16, device=x.device)
-    check(_lib.svd_silu_f32_to_bf16(_p(x), _p(out), x.numel(), int(silu), _stream()), "svd_silu_f32_to_bf16")
+    out = torch.empty(x.shape, dtype=ELEM, device=x.device)
+    check(_lib.svd_cast_f32(_p(x), _p(out), x.numel(), int(silu), _dt(out), _stream()), "svd_cast_f32")
     return out
+
+
+to_bf16 = to_elem   # historical name
 
 
 def timestep_embedding(t, dim, max_period=10000.0):
     assert t.dtype == torch.float32 and t.is_contiguous()
-    out = torch.empty((t.numel(), dim), dtype=BF16, device=t.device)
-    check(_lib.svd_timestep_embedding(_p(t), t.numel(), dim, float(max_period), _p(out), _stream()),
+    out = torch.empty((t.numel(), dim), dtype=ELEM, device=t.device)
+    check(_lib.svd_timestep_embedding(_p(t), t.numel(), dim, float(max_period), _p(out), _dt(out), _stream()),
           "svd_timestep_embedding")
     return out
 

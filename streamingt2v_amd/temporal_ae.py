@@ -104,15 +104,15 @@ class AEAttnBlock:
         assert pix % 64 == 0, "VAE mid attention expects H*W to be a multiple of 64"
         h = ops.groupnorm(x, F, pix, *self.n, 1e-6, silu=False)
         qk = ops.gemm(h, self.wqk, bias=self.bqk)                       # [F*pix, 2C]
-        key = (F, pix)
+        key = (F, pix, x.dtype)
         vt = self._vt.get(key)
         if vt is None:
-            vt = torch.zeros((F, c, pix), dtype=BF16, device=self.dev)
+            vt = torch.zeros((F, c, pix), dtype=x.dtype, device=self.dev)
             self._vt[key] = vt
         ops.gemm(h, self.wv, bias=self.bv, trans_out=dict(tok_per_frame=pix, tokens_ld=pix, out=vt))
-        o = torch.empty((F * pix, c), dtype=BF16, device=x.device)
+        o = torch.empty((F * pix, c), dtype=x.dtype, device=x.device)
         s = torch.empty((pix, pix), dtype=torch.float32, device=x.device)
-        p = torch.empty((pix, pix), dtype=BF16, device=x.device)
+        p = torch.empty((pix, pix), dtype=x.dtype, device=x.device)
         for f in range(F):
             q_f, k_f = qk[f * pix:(f + 1) * pix, :c], qk[f * pix:(f + 1) * pix, c:]
             ops.gemm(q_f, k_f, out=s)                                    # scores = q k^T  (fp32)

@@ -30,7 +30,8 @@ BF16 = torch.bfloat16
 # weight packing helpers (run once in prepare(); torch here is parameter plumbing, not the hot path)
 # ----------------------------------------------------------------------------------------------------------------
 def _dev_bf16(t, dev):
-    return t.detach().to(device=dev, dtype=torch.float32).to(BF16).contiguous()
+    """fp32 parameter -> packed 16-bit weight in the active element type (ops.ELEM)."""
+    return t.detach().to(device=dev, dtype=torch.float32).to(ops.ELEM).contiguous()
 
 
 def _dev_f32(t, dev):
@@ -232,13 +233,13 @@ class SpatialVideoTransformer:
         self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))
 
-    def _vt_buf(self, F, pix):
+    def _vt_buf(self, F, pix, x_dtype):
         """V^T staging buffer [F, C, tok_ld]; the pad beyond `pix` stays zero (never written by the GEMM)."""
         tok_ld = (pix + 63) // 64 * 64
-        key = (F, tok_ld)
+        key = (F, tok_ld, x_dtype)
         b = self._vt.get(key)
         if b is None:
-            b = torch.zeros((F, self.c, tok_ld), dtype=BF16, device=self.dev)
+            b = torch.zeros((F, self.c, tok_ld), dtype=x_dtype, device=self.dev)
             self._vt[key] = b
         return b, tok_ld
 
@@ -265,9 +266,9 @@ class SpatialVideoTransformer:
         # ---- spatial BasicTransformerBlock (attention.py:567-593) ----
         n1 = ops.layernorm(h, *self.s_ln["norm1"])
         qk = ops.gemm(n1, self.s_wqk)
-        vt, tok_ld = self._vt_buf(F, pix)
+        vt, tok_ld = self._vt_buf(F, pix, x.dtype)
         ops.gemm(n1, self.s_wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
-        a = torch.empty((M, c), dtype=BF16, device=x.device)
+        a = torch.empty((M, c), dtype=x.dtype, device=x.device)
         ops.attn_spatial(qk[:, :c], qk[:, c:], vt, a, F, pix, heads)
         v2 = ops.gemm(ops.gemm(ctx, self.s_wv2), self.s_wo2, bias=self.s_bo2, out_f32=True)      # attn2 == const/frame
         h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h)
@@ -280,7 +281,7 @@ class SpatialVideoTransformer:
         xm = ops.gemm(g, self.t_wi2, bias=self.t_bi2, residual=xm)
         n1 = ops.layernorm(xm, *self.t_ln["norm1"])
         qkv = ops.gemm(n1, self.t_wqkv)
-        at = torch.empty((M, c), dtype=BF16, device=x.device)
+        at = torch.empty((M, c), dtype=x.dtype, device=x.device)
         ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pix, heads)
         v2t = ops.gemm(ops.gemm(tctx, self.t_wv2), self.t_wo2, bias=self.t_bo2, out_f32=True)    # [B, C]
         xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pix, residual=xm)
@@ -322,7 +323,7 @@ class ConditionalModel:
         hn = ops.gemm(hn, self.wpi, bias=self.bpi)
         q = ops.gemm(hn, self.wq)
         kv = ops.gemm(cond, self.wkv)
-        a = torch.empty((F * pix, c), dtype=BF16, device=sample.device)
+        a = torch.empty((F * pix, c), dtype=sample.dtype, device=sample.device)
         ops.attn_temporal(q, kv[:, :c], kv[:, c:], a, B, T, Tc, pix, self.heads)
         a = ops.gemm(a, self.wo, bias=self.bo)
         # dropout(p=.25) on the non-conditional frames is identity in eval mode (conditioning.py:74-75)

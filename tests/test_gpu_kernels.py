@@ -9,25 +9,32 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16 = torch.bfloat16
+BF16 = torch.bfloat16      # rebound per parametrisation: the element type under test (bf16 | fp16)
+TOLF = 1.0                 # tolerance factor: fp16 has 3 more mantissa bits -> tolerances / 4
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def ops(request):
+    """Every kernel test runs once per element type of the C ABI (dtype argument)."""
+    global BF16, TOLF
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from streamingt2v_amd import ops as o
-    return o
+    BF16 = request.param
+    TOLF = 1.0 if request.param == torch.bfloat16 else 0.25
+    o.set_element_dtype(request.param)
+    yield o
+    o.set_element_dtype(torch.bfloat16)
 
 
-def rnd(*shape, scale=1.0, seed=0, dtype=BF16):
+def rnd(*shape, scale=1.0, seed=0, dtype=None):
     g = torch.Generator(device="cpu"); g.manual_seed(seed + sum(shape))
-    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+    return (torch.randn(*shape, generator=g) * scale).to(dtype or BF16).cuda()
 
 
 def check(name, got, ref, atol, rtol):
     got, ref = got.float().cpu(), ref.float().cpu()
     err = (got - ref).abs()
-    bound = atol + rtol * ref.abs()
+    bound = TOLF * (atol + rtol * ref.abs()) if atol > 1e-5 else atol + rtol * ref.abs()
     worst = (err - bound).max().item()
     print(f"[{name}] max abs err {err.max().item():.4e} (ref absmax {ref.abs().max().item():.3f}) worst margin {worst:.3e}")
     assert torch.isfinite(got).all(), f"{name}: non-finite output"
@@ -218,21 +225,21 @@ def test_layout_and_glue(ops):
     ref = torch.zeros(Fr, h * w, 32, device="cuda")
     ref[..., :4] = (x0 * sc[:, None, None, None]).flatten(2).transpose(1, 2)
     ref[..., 4:8] = x1.flatten(2).transpose(1, 2)
-    check("nchw_to_tokens", tok, ref.view(-1, 32), 1e-6, 2 ** -8)
+    check("nchw_to_tokens", tok, ref.view(-1, 32), 1e-6, 2 ** -8 * (1 if BF16 == torch.bfloat16 else 0.125))
     back = ops.tokens_to_nchw(tok, 8, Fr, h, w)
     check("tokens_to_nchw", back, ref.view(Fr, h * w, 32)[..., :8].transpose(1, 2).reshape(Fr, 8, h, w).to(BF16), 0, 0)
     a, b = rnd(50, 64, seed=40), rnd(50, 128, seed=41)
     check("concat", ops.concat_channels(a, b), torch.cat([a, b], 1), 0, 0)
     c = rnd(50, 64, seed=42)
-    check("add_rows", ops.add_rows(a, c), a.float() + c.float(), 1e-6, 2 ** -8)
+    check("add_rows", ops.add_rows(a, c), a.float() + c.float(), 1e-6, 2 ** -8 * (1 if BF16 == torch.bfloat16 else 0.125))
     t = torch.tensor([0.0, 1.5, -0.7, 12.0], device="cuda")
     emb = ops.timestep_embedding(t, 320)
     half = 160
     freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half).cuda()
     args = t[:, None] * freqs[None]
-    check("timestep_embedding", emb, torch.cat([args.cos(), args.sin()], -1), 1e-3, 2 ** -8)
+    check("timestep_embedding", emb, torch.cat([args.cos(), args.sin()], -1), 1e-3, 2 ** -8 * (1 if BF16 == torch.bfloat16 else 0.125))
     v = rnd(7, 33, seed=43, dtype=torch.float32)
-    check("silu->bf16", ops.to_bf16(v, silu=True), F.silu(v), 1e-6, 2 ** -8)
+    check("silu->bf16", ops.to_bf16(v, silu=True), F.silu(v), 1e-6, 2 ** -8 * (1 if BF16 == torch.bfloat16 else 0.125))
 
 
 def test_edm_euler_step(ops):
