@@ -10,6 +10,8 @@ struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
     static constexpr bool GLDS = GLDS_, TRANS = TRANS_;
     static constexpr int NT = WM * WN * 64;
+    // register budget: 4-wave workgroups with <= 64 accumulator registers per lane must fit twice per SIMD (2 WG / CU)
+    static constexpr int MIN_WAVES_PER_SIMD = (WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? 2 : 1;
     static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     static constexpr int ROWB = BK * 2;       // bytes per LDS row
     static constexpr int SLOTS = BK / 8;      // 16-byte slots per row
@@ -19,6 +21,11 @@ struct GemmCfg {
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    // row-contiguous epilogue: per-wave fp32 staging slice of one 32x32 fragment (row stride 36 floats)
+    static constexpr int EPI_SROW = 32 + 4;
+    static constexpr int EPI_WAVE_BYTES = 32 * EPI_SROW * 4;
+    static constexpr bool EPI_DEDICATED = (WM * WN * EPI_WAVE_BYTES > STAGE_BYTES);   // else: reuse the consumed stage buffer
+    static constexpr int LAUNCH_LDS = LDS_BYTES + (EPI_DEDICATED ? WM * WN * EPI_WAVE_BYTES : 0);
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of rows-per-pass");
     static_assert(RPP % 16 == 0, "swizzle assumes pass stride multiple of 16 rows");
 };
