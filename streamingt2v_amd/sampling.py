@@ -61,7 +61,10 @@ class LinearPredictionGuider:
 class EulerEDMSampler:
     """30 Euler steps on the AYS schedule with per-frame linear guidance (config.yaml:139-158)."""
 
-    def __init__(self, num_steps=30, num_frames=25, min_scale=1.5, max_scale=3.0, discretization=None):
+    def __init__(self, num_steps=30, num_frames=25, min_scale=1.5, max_scale=3.0, discretization=None, cfg_exchange=None):
+        """cfg_exchange: optional streamingt2v_amd.parallel.CfgPairExchange -- this rank then evaluates only ITS half
+        of the CFG batch per step and all-gathers the raw network outputs with its partner (exact 2-way split)."""
+        self.cfg_exchange = cfg_exchange
         self.num_steps = num_steps
         self.discretization = discretization or AlignYourSteps()
         self.guider = LinearPredictionGuider(max_scale=max_scale, num_frames=num_frames, min_scale=min_scale)
@@ -84,11 +87,19 @@ class EulerEDMSampler:
         if g is None:
             g = self.guider.scale.to(dev).float().contiguous()
             self._gscale[dev] = g
-        c2 = {k: torch.cat((uc[k], cond[k]), 0).float().contiguous() for k in ("vector", "crossattn", "concat")}
+        ex = self.cfg_exchange
+        if ex is None:
+            c2 = {k: torch.cat((uc[k], cond[k]), 0).float().contiguous() for k in ("vector", "crossattn", "concat")}
+        else:
+            half = (uc, cond)[ex.half]
+            c2 = {k: half[k].float().contiguous() for k in ("vector", "crossattn", "concat")}
+            model_kwargs = dict(model_kwargs, batch_size=1)
         for i in range(len(sig) - 1):
             s = float(np.float32(sig[i]))                     # s_in * sigmas[i] is fp32 in the reference
             s_next = float(np.float32(sig[i + 1]))
             _, _, c_in, c_noise = self.scaling(s)
             net = wrapper.forward_fused(x, c_in, c_noise, c2, **model_kwargs)   # [2T*pix, 4] fp32 tokens
+            if ex is not None:
+                net = ex.gather(net)                          # (uncond | cond) from the two ranks of the pair
             ops.edm_euler_step(x, net, g, s, s_next)
         return x

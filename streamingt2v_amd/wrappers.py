@@ -41,14 +41,16 @@ class StreamingWrapper:
             ctx_ctrl = reduce_rows(context[:, :1], 1)                 # only CLIP token 0 (wrappers.py:39)
             y_ctrl = reduce_rows(y, 1)
             # ... and the pixel-space control frames, repeated for both CFG halves (wrappers.py:45-48)
-            cond = ctrl_frames.repeat(2, *([1] * (ctrl_frames.dim() - 1))).flatten(0, 1)
+            # "(2 B) F ..." in the reference (B = 1 video, CFG batch 2); one copy per batch element here so that a rank
+            # holding a single CFG half (parallel.CfgPairExchange) repeats once
+            cond = ctrl_frames.repeat(batch_size // ctrl_frames.shape[0], *([1] * (ctrl_frames.dim() - 1))).flatten(0, 1)
             cond = self._cond_cached(ctrl_frames, cond)
             hs_c, mid_c = self.controlnet.forward_tokens(x_ctrl, t_ctrl, cond, ctx_ctrl, y_ctrl, Tc, H, W)
         return self.diffusion_model.forward_tokens(x_tok, t, context, y, T, H, W, hs_c, mid_c, Tc)
 
     def _cond_cached(self, ctrl_frames, cond):
         # keep ONE repeated tensor per ctrl_frames object so ControlNet.embed_condition can recognise it
-        key = (ctrl_frames.data_ptr(), tuple(ctrl_frames.shape), ctrl_frames._version)
+        key = (ctrl_frames.data_ptr(), tuple(ctrl_frames.shape), ctrl_frames._version, tuple(cond.shape))
         if getattr(self, "_cond_key", None) != key:
             self._cond_key, self._cond_val = key, cond.float().contiguous()
         return self._cond_val
@@ -74,19 +76,20 @@ class StreamingWrapper:
     # ---- fused entry point used by our EulerEDMSampler ---------------------------------------------------------
     def forward_fused(self, x, c_in, c_noise, c2, *, batch_size, num_video_frames, ctrl_frames=None,
                       image_only_indicator=None, **_ignored):
-        """x [T,4,h,w] fp32 (UNscaled sampler state); c2: CFG-doubled cond dict.  Returns raw network output tokens
-        [2T*h*w, 4] fp32 for (uncond | cond), i.e. network(cat([x]*2) * c_in, c_noise, c2)."""
+        """x [T,4,h,w] fp32 (UNscaled sampler state); c2: cond dict with batch_size*T rows (batch_size = 2: CFG-doubled
+        (uncond | cond); batch_size = 1: ONE CFG half, used by the CFG-pair split over two ranks).  Returns the raw network
+        output tokens [batch_size*T*h*w, 4] fp32, i.e. network(cat([x]*batch_size) * c_in, c_noise, c2)."""
         T, _, H, W = x.shape
-        key = (x.device, T)
+        key = (x.device, T, batch_size)
         aux = getattr(self, "_aux", {}).get(key)
         if aux is None:
-            aux = (torch.empty((2 * T,), dtype=torch.float32, device=x.device),
-                   torch.empty((2 * T,), dtype=torch.float32, device=x.device))
+            aux = (torch.empty((batch_size * T,), dtype=torch.float32, device=x.device),
+                   torch.empty((batch_size * T,), dtype=torch.float32, device=x.device))
             self._aux = getattr(self, "_aux", {})
             self._aux[key] = aux
         scale, tvec = aux
         scale.fill_(c_in)
         tvec.fill_(c_noise)
-        x2 = torch.cat([x, x], 0)
+        x2 = torch.cat([x] * batch_size, 0) if batch_size > 1 else x
         x_tok = ops.nchw_to_tokens(x2, c2["concat"], scale, 32)          # (x * c_in | concat) -> 8 ch, padded to 32
         return self._run(x_tok, tvec, c2["crossattn"], c2["vector"], batch_size, num_video_frames, H, W, ctrl_frames)

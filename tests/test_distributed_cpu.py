@@ -1,0 +1,92 @@
+"""CPU suite, part 4: the N>1 paths with torch.distributed gloo, world_size 2 (no GPU).
+
+  * randomized blending: single-process product loop == oracle restatement (bit-exact) and the window-sharded
+    all-gather version == single process, on 2 ranks;
+  * CFG-pair exchange: each rank evaluates one CFG half, all-gather == the 2-batch evaluation;
+  * bench timing helper: max over ranks."""
+import os
+import random
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _denoise(idx, w):                      # deterministic stand-in for UNet + CFG + DDIM step of a window
+    return w * (1.0 + 0.125 * idx) + 0.5 * idx
+
+
+def _case():
+    g = torch.Generator(); g.manual_seed(7)
+    return torch.randn(1, 4, 90, 3, 5, generator=g), 38, 12, 3          # shipped: 38 / 12, 3 windows over 90 frames
+
+
+def test_blending_matches_oracle_and_reference_quirks():
+    from oracle.blending_oracle import randomized_blending_step
+    from streamingt2v_amd.blending import blend_step, chunk_starts
+    lat, cs, ov, n = _case()
+    a = blend_step(lat, _denoise, cs, ov, n, random.Random(33))
+    b = randomized_blending_step(lat, _denoise, cs, ov, n, random.Random(33))
+    assert torch.equal(a, b)
+    assert chunk_starts(90, 38, 12, 3) == [0, 26, 52]
+    with pytest.raises(NotImplementedError):                           # 100 frames do not divide
+        blend_step(torch.zeros(1, 4, 88, 2, 2), _denoise, cs, ov, n, random.Random(1))
+    with pytest.raises(NotImplementedError):
+        randomized_blending_step(torch.zeros(1, 4, 88, 2, 2), _denoise, cs, ov, n, random.Random(1))
+    # overlap 0 draws no random numbers (pipeline_i2vgen_xl.py:894-898)
+    r = random.Random(5); st = r.getstate()
+    blend_step(torch.zeros(1, 4, 20, 2, 2), _denoise, 10, 0, 2, r)
+    assert r.getstate() == st
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from streamingt2v_amd import parallel
+    from streamingt2v_amd.blending import blend_step, blend_step_sharded
+    assert parallel.init_from_env(backend="gloo") == world
+    try:
+        lat, cs, ov, n = _case()
+        ref = blend_step(lat, _denoise, cs, ov, n, random.Random(33))
+        got = blend_step_sharded(lat, _denoise, cs, ov, n, random.Random(33))
+        ok_blend = torch.equal(ref, got)
+        # 5 windows on 2 ranks: uneven sharding with a padded slot
+        lat5 = torch.arange(1 * 2 * 46 * 2 * 2, dtype=torch.float32).reshape(1, 2, 46, 2, 2)
+        ok_blend5 = torch.equal(blend_step(lat5, _denoise, 14, 6, 5, random.Random(3)),
+                                blend_step_sharded(lat5, _denoise, 14, 6, 5, random.Random(3)))
+        # CFG pair: net(x2, cond2) evaluated half per rank
+        g = torch.Generator(); g.manual_seed(1)
+        x = torch.randn(6, 4, generator=g)
+        cond = torch.stack([torch.zeros(6, 4), torch.ones(6, 4)])       # [uncond | cond]
+        net = lambda xx, cc: xx * 2.0 + cc * 3.0
+        full = torch.cat([net(x, cond[0]), net(x, cond[1])], 0)
+        ex = parallel.CfgPairExchange()
+        ok_cfg = torch.equal(ex.gather(net(x, cond[ex.half])), full)
+        tmax = parallel.max_over_ranks(1.0 + rank)
+        parallel.barrier()
+        out.put((rank, ok_blend, ok_blend5, ok_cfg, tmax, parallel.shard_items(5, rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_paths():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_blend, ok_blend5, ok_cfg, tmax, items in res:
+        assert ok_blend and ok_blend5 and ok_cfg
+        assert tmax == 2.0
+        assert items == ([0, 2, 4] if rank == 0 else [1, 3])
