@@ -116,7 +116,10 @@ def main():
     sig30 = AlignYourSteps(sigma_max=700.0)(30, device="cpu")
     sig4 = AlignYourSteps(sigma_max=700.0)(4, device="cpu")
     assert maxerr(sig30, O.ays_sigmas(30)) == 0.0 and maxerr(sig4, O.ays_sigmas(4)) == 0.0
-    torch.save({"z": z_ref.clone(), "sigmas30": sig30, "sigmas4": sig4}, os.path.join(OUT, "sampler_tiny.pt"))
+    from models.svd.sgm.modules.diffusionmodules.discretizer import EDMDiscretization
+    edm25 = EDMDiscretization(sigma_min=0.002, sigma_max=700.0, rho=7.0)(25, device="cpu")
+    assert maxerr(edm25, O.edm_sigmas(25)) == 0.0
+    torch.save({"z": z_ref.clone(), "sigmas30": sig30, "sigmas4": sig4, "edm25": edm25}, os.path.join(OUT, "sampler_tiny.pt"))
 
     # ---------------- temporal VAE decoder ----------------
     t0 = time.time()

@@ -353,6 +353,13 @@ def ays_sigmas(n):
     return torch.cat([torch.from_numpy(new), torch.zeros(1, dtype=torch.float64)])
 
 
+def edm_sigmas(n, sigma_min=0.002, sigma_max=700.0, rho=7.0):
+    """EDMDiscretization.get_sigmas + append zero, sgm discretizer.py:27-38 (fp32 ramp); the schedule of the first chunk."""
+    ramp = torch.linspace(0, 1, n)
+    mn, mx = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    return torch.cat([(mx + ramp * (mn - mx)) ** rho, torch.zeros(1)])
+
+
 def vscaling_edm(sigma):
     """VScalingWithEDMcNoise, denoiser_scaling.py:51-59 -> (c_skip, c_out, c_in, c_noise)."""
     return 1.0 / (sigma ** 2 + 1.0), -sigma / (sigma ** 2 + 1.0) ** 0.5, 1.0 / (sigma ** 2 + 1.0) ** 0.5, 0.25 * sigma.log()

@@ -42,6 +42,24 @@ class AlignYourSteps:
         return np.concatenate([s, [0.0]]) if do_append_zero else s
 
 
+class EDMDiscretization:
+    """Karras rho-schedule: (smax^(1/rho) + ramp * (smin^(1/rho) - smax^(1/rho)))^rho.
+    sgm discretizer.py:27-38; identical to diffusers' EulerDiscreteScheduler(use_karras_sigmas) that the reference's first
+    chunk runs through StableVideoDiffusionPipeline (sigma_min 0.002, sigma_max 700, 25 steps; streaming_svd.py:388-390)."""
+
+    def __init__(self, sigma_min=0.002, sigma_max=700.0, rho=7.0):
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def get_sigmas(self, n):
+        ramp = np.linspace(0, 1, n, dtype=np.float32)           # the reference builds the ramp with torch.linspace (fp32)
+        mn, mx = self.sigma_min ** (1 / self.rho), self.sigma_max ** (1 / self.rho)
+        return ((mx + ramp * (mn - mx)) ** self.rho).astype(np.float64)
+
+    def __call__(self, n, do_append_zero=True):
+        s = self.get_sigmas(n)
+        return np.concatenate([s, [0.0]]) if do_append_zero else s
+
+
 class VScalingWithEDMcNoise:
     def __call__(self, sigma):
         s2 = sigma * sigma + 1.0

@@ -49,6 +49,32 @@ class StreamingSVD:
                                  num_video_frames=T, ctrl_frames=ctrl_frames)
         return self.decode_first_stage(samples_z, clamp=True)          # torch.clamp(-1, 1) fused (streaming_svd.py:220)
 
+    @torch.no_grad()
+    def _generate_initial_chunk(self, c, uc, noise, num_steps=25, min_scale=1.0, max_scale=3.0):
+        """Chunk 0 natively: the reference delegates the first 25 frames to diffusers'
+        StableVideoDiffusionPipeline (streaming_svd.py:388-390) -- the same UNet without ControlNet/CAM, an Euler step on
+        the Karras/EDM schedule (25 steps) and per-frame guidance 1.0 -> 3.0, decoded in groups of 8 (decode_chunk_size=8)."""
+        from .sampling import EDMDiscretization
+        T = self.sampler.guider.num_frames
+        sampler = EulerEDMSampler(num_steps=num_steps, num_frames=T, min_scale=min_scale, max_scale=max_scale,
+                                  discretization=EDMDiscretization(), cfg_exchange=self.sampler.cfg_exchange)
+        x = noise.clone().float().contiguous()
+        z = sampler(self.inference_model, x, c, uc, batch_size=2, num_video_frames=T, ctrl_frames=None)
+        return self.decode_first_stage(z, clamp=True)
+
+    @torch.no_grad()
+    def image_to_video(self, conditioner, image, num_frames, noises, num_steps=None):
+        """Mirror of StreamingSVD.image_to_video + inference_i2v.StreamingPipeline.image_to_video's chunk arithmetic
+        (streaming_svd.py:359-402, inference_i2v.py:179-190): first chunk, then ceil((N - 25) / (25 - 7)) AR chunks,
+        result cut to num_frames.  image [3, H, W] in [-1, 1]; conditioner(frame) -> (c, uc); noises: one [T,4,h,w] per chunk."""
+        T, Tc = self.sampler.guider.num_frames, self.num_conditional_frames
+        n_ar = max(0, math.ceil((num_frames - T) / (T - Tc)))
+        assert len(noises) >= 1 + n_ar
+        c, uc = conditioner(image)
+        first = self._generate_initial_chunk(c, uc, noises[0])
+        video = self._autoregressive_generation(first, conditioner, n_ar, noises[1:], num_steps=num_steps)
+        return video[:num_frames]
+
     @staticmethod
     def extract_ctrl_frames(video, num_conditional_frames):
         """Last frames of the previous chunk as [1, Tc, 3, H, W] (streaming_svd.py:263-290)."""

@@ -28,7 +28,8 @@ class StreamingWrapper:
     def _run(self, x_tok, t, context, y, batch_size, T, H, W, ctrl_frames):
         Tc = self.num_frame_conditioning
         hs_c = mid_c = None
-        if self.diffusion_model.controlnet_mode:
+        # no control frames (first chunk: plain SVD, video_model.py:582,603 with hs_control_* = None) -> UNet only
+        if self.diffusion_model.controlnet_mode and ctrl_frames is not None:
             # ControlNet sees the first Tc frames of each CFG half (wrappers.py:28-42) ...
             pix = H * W
 

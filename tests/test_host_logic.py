@@ -63,6 +63,12 @@ def test_schedule_and_scaling_match_oracle():
     from streamingt2v_amd.sampling import AlignYourSteps, EulerEDMSampler, VScalingWithEDMcNoise
     for n in (2, 4, 25, 30):
         assert np.array_equal(AlignYourSteps()(n), O.ays_sigmas(n).numpy())
+    import os
+    from streamingt2v_amd.sampling import EDMDiscretization
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_tiny.pt"))
+    np.testing.assert_allclose(EDMDiscretization()(25), gold["edm25"].double().numpy(), rtol=2e-6)     # reference's EDMDiscretization
+    np.testing.assert_allclose(EDMDiscretization()(25), O.edm_sigmas(25).double().numpy(), rtol=2e-6)
+    assert abs(EDMDiscretization()(25)[0] - 700.0) < 1e-3 and abs(EDMDiscretization()(25)[24] - 0.002) < 1e-6   # fp32 pow, like the reference
     s = EulerEDMSampler(num_steps=30, num_frames=25)
     assert torch.equal(s.guider.scale, torch.linspace(1.5, 3.0, 25))
     for sg in (700.0, 1.0, 0.002):
@@ -95,3 +101,29 @@ def test_autoregressive_bookkeeping():
     assert torch.equal(seen[0][1][0], init[-7:])              # first ctrl frames = tail of chunk 0
     assert torch.allclose(seen[1][1][0, :, 0, 0, 0], 1.0 + torch.arange(18, 25) / 100.0)   # then tail of chunk 1
     assert torch.allclose(out[25:43, 0, 0, 0], 1.0 + torch.arange(7, 25) / 100.0)          # overlap frames dropped
+
+
+def test_image_to_video_chunk_arithmetic():
+    """inference_i2v.py:179-190: 100 diffusion-stage frames = chunk 0 (25) + ceil((100-25)/18) = 5 AR chunks, cut to 100."""
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+
+    class FakeSampler:
+        cfg_exchange = None
+        class guider:
+            num_frames = 25
+
+    calls = []
+
+    class Model(StreamingSVD):
+        def _generate_initial_chunk(self, c, uc, noise, **kw):
+            calls.append("init")
+            return torch.zeros(25, 3, 2, 2)
+        def _generate_conditional_output(self, c, uc, ctrl_frames, noise, num_steps=None):
+            calls.append("ar")
+            return torch.ones(25, 3, 2, 2) * len(calls)
+
+    m = Model(None, None, FakeSampler(), num_conditional_frames=7)
+    out = m.image_to_video(lambda a: ({}, {}), torch.zeros(3, 2, 2), 100, [None] * 6)
+    assert calls == ["init"] + ["ar"] * 5 and out.shape[0] == 100
+    out = m.image_to_video(lambda a: ({}, {}), torch.zeros(3, 2, 2), 25, [None])
+    assert out.shape[0] == 25
