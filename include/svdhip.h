@@ -90,6 +90,7 @@ typedef struct svd_gemm_args {
     /* tuning: 0 = heuristic, else explicit tile config id (see svd_gemm_num_configs) */
     int32_t tile_cfg;
     int32_t dtype;                        /* SVD_DTYPE_BF16 | SVD_DTYPE_F16 : A, W, R, S and 16-bit outputs */
+    uint64_t* dbg_cycles;                 /* optional (NULL in production): 8 x u64 phase cycle counters of block 0 / wave 0 */
 } svd_gemm_args;
 
 int svd_gemm(const svd_gemm_args* args, svd_stream_t stream);

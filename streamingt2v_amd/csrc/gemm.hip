@@ -39,7 +39,7 @@ extern "C" int svd_gemm_pick_config(const svd_gemm_args* args) { return args ? p
 
 extern "C" int svd_gemm_config_info(int cfg, int* bm, int* bn, int* threads, int* lds_bytes) {
     switch (cfg) {
-#define X(id, bm_, bn_, wm, wn, bk, glds, tr) case id: info<Cfg##id>(bm, bn, threads, lds_bytes); return SVD_OK;
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: info<Cfg##id>(bm, bn, threads, lds_bytes); return SVD_OK;
         SVD_GEMM_CONFIGS(X)
 #undef X
     }
@@ -49,7 +49,7 @@ extern "C" int svd_gemm_config_info(int cfg, int* bm, int* bn, int* threads, int
 extern "C" int svd_gemm_config_valid(const svd_gemm_args* args, int cfg) {
     if (!args) return SVD_EINVAL;
     switch (cfg) {
-#define X(id, bm_, bn_, wm, wn, bk, glds, tr) case id: return cfg_ok<Cfg##id>(*args) ? 1 : 0;
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return cfg_ok<Cfg##id>(*args) ? 1 : 0;
         SVD_GEMM_CONFIGS(X)
 #undef X
     }

@@ -5,7 +5,7 @@
 namespace svd_gemm_detail {
 
 
-template <int BM_, int BN_, int WM_, int WN_, int BK_, bool GLDS_, bool TRANS_>
+template <int BM_, int BN_, int WM_, int WN_, int BK_, bool GLDS_, bool TRANS_, int NS_ = 2, bool DELAY_ = false>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
     static constexpr bool GLDS = GLDS_, TRANS = TRANS_;
@@ -20,38 +20,56 @@ struct GemmCfg {
     static constexpr int PA = BM / RPP, PB = BN / RPP;
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int NSTAGE = NS_;        // LDS ring depth: the load stream runs NSTAGE-1 K tiles ahead of the MFMAs
+    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
     // row-contiguous epilogue: per-wave fp32 staging slice of one 32x32 fragment (row stride 36 floats)
     static constexpr int EPI_SROW = 32 + 4;
     static constexpr int EPI_WAVE_BYTES = 32 * EPI_SROW * 4;
-    static constexpr bool EPI_DEDICATED = (WM * WN * EPI_WAVE_BYTES > STAGE_BYTES);   // else: reuse the consumed stage buffer
-    static constexpr int LAUNCH_LDS = LDS_BYTES + (EPI_DEDICATED ? WM * WN * EPI_WAVE_BYTES : 0);
+    // delayed epilogue: the finished tile's passes run inside the next tile's K loop (needs a 2nd accumulator set: <= 64 regs)
+    static constexpr bool DELAYED_EPI = DELAY_ && !TRANS_ && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64);
+    static constexpr bool EPI_DEDICATED = DELAYED_EPI || (WM * WN * EPI_WAVE_BYTES > STAGE_BYTES);   // else: reuse the consumed stage buffer
+    // aux slots: bias slice + per-frame vectors of up to AUX_NRV frames, DMA'd at tile setup (2 slots: current / prefetched tile)
+    static constexpr int AUX_NRV = 4;
+    static constexpr int AUX_INSTR = (BN + 255) / 256;
+    static constexpr int AUX_SLOT_BYTES = (1 + AUX_NRV) * AUX_INSTR * 1024;
+    static constexpr int AUX_OFF = LDS_BYTES + (EPI_DEDICATED ? WM * WN * EPI_WAVE_BYTES : 0);
+    static constexpr int AUX_SLOTS = NSTAGE + (DELAYED_EPI ? 1 : 0);   // one per tile the load stream can be ahead (+1: the delayed tile)
+    static constexpr int LAUNCH_LDS = AUX_OFF + (TRANS_ ? 0 : AUX_SLOTS * AUX_SLOT_BYTES);
+    static_assert(LAUNCH_LDS <= 160 * 1024, "tile configuration exceeds the 160 KiB LDS of a CU");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of rows-per-pass");
     static_assert(RPP % 16 == 0, "swizzle assumes pass stride multiple of 16 rows");
 };
 
 // ---- configuration table ---------------------------------------------------------------------------------
-//        id  BM   BN   WM WN BK  GLDS   TRANS
+//        id  BM   BN   WM WN BK  GLDS   TRANS  NSTAGE
+#ifndef SVD_GEMM_CONFIGS   /* a test translation unit may predefine a reduced table */
 #define SVD_GEMM_CONFIGS(X)                                                                           \
-    X(1, 128, 128, 2, 2, 64, true, false)  /* default: 4 waves, 64x64 per wave, 2 WG/CU            */ \
-    X(2, 256, 128, 4, 2, 64, true, false)  /* 8 waves, 64x64 per wave                              */ \
-    X(3, 128, 64, 2, 2, 64, true, false)   /* narrow N                                             */ \
-    X(4, 128, 320, 2, 2, 64, true, false)  /* N = 320 / 960 exactly, 64x160 per wave               */ \
-    X(5, 128, 128, 2, 2, 32, true, false)  /* K (or cin) multiple of 32 only                       */ \
-    X(6, 128, 128, 2, 2, 64, false, false) /* register-staged fallback of 1                        */ \
-    X(7, 128, 128, 2, 2, 64, true, true)   /* transposed output (V^T for attention)                */ \
-    X(8, 256, 256, 4, 2, 64, true, false)  /* 8 waves, 64x128 per wave                             */ \
-    X(9, 128, 256, 2, 2, 64, true, false)  /* 4 waves, 64x128 per wave                             */ \
-    X(10, 256, 128, 2, 2, 64, true, false) /* 4 waves, 128x64 per wave                             */ \
-    X(11, 256, 256, 2, 2, 64, true, false) /* 4 waves, 128x128 per wave (1 wave / SIMD)            */ \
-    X(12, 64, 128, 2, 2, 64, true, false)  /* small M                                              */ \
-    X(13, 128, 160, 4, 1, 64, true, false) /* N = 320 as 2 tiles, 32x160 per wave                  */ \
-    X(14, 256, 160, 4, 1, 64, true, false) /* N = 320 as 2 tiles, 64x160 per wave                  */ \
-    X(15, 256, 64, 4, 1, 64, true, false)  /* N = 320 as 5 tiles, 64x64 per wave                   */ \
-    X(16, 128, 192, 2, 2, 64, true, false) /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */
-constexpr int kNumCfg = 16;
+    X(1, 128, 128, 2, 2, 64, true, false, 2)  /* default: 4 waves, 64x64 per wave, 2 WG/CU            */ \
+    X(2, 256, 128, 4, 2, 64, true, false, 2)  /* 8 waves, 64x64 per wave                              */ \
+    X(3, 128, 64, 2, 2, 64, true, false, 2)   /* narrow N                                             */ \
+    X(4, 128, 320, 2, 2, 64, true, false, 2)  /* N = 320 / 960 exactly, 64x160 per wave               */ \
+    X(5, 128, 128, 2, 2, 32, true, false, 2)  /* K (or cin) multiple of 32 only                       */ \
+    X(6, 128, 128, 2, 2, 64, false, false, 2) /* register-staged fallback of 1                        */ \
+    X(7, 128, 128, 2, 2, 64, true, true, 2)   /* transposed output (V^T for attention)                */ \
+    X(8, 256, 256, 4, 2, 64, true, false, 2)  /* 8 waves, 64x128 per wave                             */ \
+    X(9, 128, 256, 2, 2, 64, true, false, 2)  /* 4 waves, 64x128 per wave                             */ \
+    X(10, 256, 128, 2, 2, 64, true, false, 2) /* 4 waves, 128x64 per wave                             */ \
+    X(11, 256, 256, 2, 2, 64, true, false, 2) /* 4 waves, 128x128 per wave (1 wave / SIMD)            */ \
+    X(12, 64, 128, 2, 2, 64, true, false, 2)  /* small M                                              */ \
+    X(13, 128, 160, 4, 1, 64, true, false, 2) /* N = 320 as 2 tiles, 32x160 per wave                  */ \
+    X(14, 256, 160, 4, 1, 64, true, false, 2) /* N = 320 as 2 tiles, 64x160 per wave                  */ \
+    X(15, 256, 64, 4, 1, 64, true, false, 2)  /* N = 320 as 5 tiles, 64x64 per wave                   */ \
+    X(16, 128, 192, 2, 2, 64, true, false, 2) /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */ \
+    X(17, 256, 256, 4, 2, 32, true, false, 3) /* 3-stage ring, BK 32: loads 2 K tiles ahead (133 KB)          */ \
+    X(18, 256, 128, 4, 2, 64, true, false, 3) /* 3-stage ring (144 KB)                                        */ \
+    X(19, 256, 128, 4, 2, 64, true, false, 12) /* delayed epilogue (stores of tile t inside the K loop of t+1)   */ \
+    X(20, 128, 128, 2, 2, 64, true, false, 12) /* delayed epilogue, 4 waves                                      */ \
+    X(21, 128, 128, 2, 2, 32, true, false, 12) /* delayed epilogue, BK 32 (2 WG/CU)                              */ \
+    X(22, 256, 128, 4, 2, 32, true, false, 12) /* delayed epilogue, BK 32, 8 waves                               */
+#endif
+constexpr int kNumCfg = 22;
 
-#define X(id, bm, bn, wm, wn, bk, glds, tr) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr>;
+#define X(id, bm, bn, wm, wn, bk, glds, tr, ns) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr, (ns) % 10, ((ns) >= 10)>;   /* ns >= 10: delayed epilogue */
 SVD_GEMM_CONFIGS(X)
 #undef X
 

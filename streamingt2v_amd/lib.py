@@ -52,6 +52,7 @@ class GemmArgs(C.Structure):
         ("tok_per_frame", C.c_int32), ("tokens_ld", C.c_int64),
         ("tile_cfg", C.c_int32),
         ("dtype", C.c_int32),
+        ("dbg_cycles", C.c_void_p),
     ]
 
 

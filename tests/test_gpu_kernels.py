@@ -42,7 +42,7 @@ def check(name, got, ref, atol, rtol):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 320, 320), (77, 960, 64), (4096, 640, 1280)])
 def test_gemm_plain(ops, cfg, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
@@ -81,7 +81,30 @@ def test_gemm_epilogues(ops):
     check("gemm silu", out, F.silu(a.float() @ w.float().t() + bias), 2e-2, 1e-2)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 8, 17, 19, 20, 21, 22])
+@pytest.mark.parametrize("K", [32, 64, 128, 704])
+@pytest.mark.parametrize("M", [40000, 32768])
+def test_gemm_many_tiles_per_workgroup(ops, cfg, K, M):
+    """More tiles than resident workgroups: exercises the persistent loop, the aux-slot ring and the delayed epilogue
+    (a tile's stores issued inside the next tile's K loop; K shorter / longer than the number of epilogue passes)."""
+    if K % 64 and cfg not in (17, 21, 22):
+        pytest.skip("config needs K % 64 == 0")
+    N, rpv = 1024, 1000
+    a, w = rnd(M, K, seed=30), rnd(N, K, scale=K ** -0.5, seed=31)
+    bias = rnd(N, seed=32, dtype=torch.float32)
+    rowvec = rnd((M + rpv - 1) // rpv, N, seed=33, dtype=torch.float32)
+    R, S = rnd(M, N, seed=34), rnd(M, N, seed=35)
+    mm = a.float() @ w.float().t()
+    base = mm + bias + rowvec.repeat_interleave(rpv, 0)[:M] + R.float()
+    out = ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_vec=rpv, residual=R, tile_cfg=cfg)
+    check(f"many tiles cfg{cfg} K{K} +bias+rowvec+residual", out, base, 3e-2, 1e-2)
+    out = ops.gemm(a, w, bias=bias, residual=R, blend=(0.25, S), silu=True, tile_cfg=cfg)
+    check(f"many tiles cfg{cfg} K{K} blend+silu", out, F.silu(0.25 * S.float() + 0.75 * (mm + bias + R.float())), 3e-2, 1e-2)
+    out = ops.gemm(a, w, out_f32=True, tile_cfg=cfg)
+    check(f"many tiles cfg{cfg} K{K} f32", out, mm, 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 9, 10, 11, 12, 17, 18, 19, 20, 21, 22])
 def test_gemm_geglu(ops, cfg):
     from streamingt2v_amd.video_model import pack_geglu
     M, C = 300, 320

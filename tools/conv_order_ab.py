@@ -13,7 +13,7 @@ for (Fr,H,W,cin,cout) in [(50,72,128,320,320),(50,36,64,640,640),(50,18,32,1280,
     M=Fr*H*W; x=torch.randn(M,cin,device="cuda").to(torch.bfloat16); w=(torch.randn(cout,9*cin,device="cuda")*(9*cin)**-0.5).to(torch.bfloat16)
     out=torch.empty(M,cout,device="cuda",dtype=torch.bfloat16)
     line=f"conv {Fr}x{H}x{W} {cin}->{cout}:"
-    for cfg in (1,2,8):
+    for cfg in (2,8,17,18,20):
         r=[]
         for flag in (0, 1<<28):
             a=L.GemmArgs(); a.A,a.lda=x.data_ptr(),cin; a.W,a.ldw=w.data_ptr(),9*cin; a.M,a.N,a.K=M,cout,9*cin; a.a_mode=1; a.cin=cin
