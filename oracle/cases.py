@@ -69,3 +69,24 @@ def tiny_sampler_inputs():
 def tiny_vae_inputs():
     g = _gen(99)
     return dict(z=torch.randn(TINY_VAE["T"], 4, TINY_VAE["h"], TINY_VAE["w"], generator=g))
+
+
+# ---- I2VGen-XL enhancer (row A12): tiny configuration of code/i2v_enhance/unet_i2vgen_xl.py:188-211 ----
+# 3 levels (cross-attn, cross-attn, plain), one layer per block, odd latent height so that the up path has to forward the
+# upsample size (the shipped 90x160 latent does too: 90 % 8 != 0).
+TINY_I2V = dict(block_out_channels=(64, 128, 128), down_block_types=("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
+                up_block_types=("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"), layers_per_block=1,
+                norm_num_groups=32, cross_attention_dim=128, attention_head_dim=64, F=6, h=9, w=12, text_tokens=7)
+
+
+def tiny_i2v_kwargs():
+    return {k: TINY_I2V[k] for k in ("block_out_channels", "down_block_types", "up_block_types", "layers_per_block",
+                                     "norm_num_groups", "cross_attention_dim", "attention_head_dim")}
+
+
+def tiny_i2v_inputs():
+    g = _gen(777)
+    B, Fr, h, w, cd = 2, TINY_I2V["F"], TINY_I2V["h"], TINY_I2V["w"], TINY_I2V["cross_attention_dim"]
+    return dict(sample=torch.randn(B, 4, Fr, h, w, generator=g), t=torch.tensor(481), fps=torch.tensor([8, 8]),
+                image_latents=torch.randn(B, 4, Fr, h, w, generator=g) * 0.7,
+                image_embeddings=torch.randn(B, cd, generator=g), text=torch.randn(B, TINY_I2V["text_tokens"], cd, generator=g))

@@ -18,7 +18,7 @@ template <int NW, class E>
 __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ Vt, int64_t tok_ld, svd_bf16* __restrict__ O, int64_t ldo,
-    int frames, int n_tok, int heads, int qblocks) {
+    int frames, int n_q, int n_tok /* keys */, int kv_div, int heads, int qblocks) {
     constexpr int NT = NW * 64;
     constexpr int BQ = NW * 32;
     constexpr int KT = 64;                 // keys per tile
@@ -42,14 +42,17 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
     const int fh = wgid / qblocks, qb = wgid - fh * qblocks;
     const int f = fh / heads, h = fh - f * heads;
 
-    const svd_bf16* Qf = Q + (int64_t)f * n_tok * ldq + h * 64;
-    const svd_bf16* Kf = K + (int64_t)f * n_tok * ldk + h * 64;
-    const svd_bf16* Vf = Vt + ((int64_t)f * heads + h) * 64 * tok_ld;
+    // cross-attention: n_q queries per frame attend to the n_tok keys of key/value set f / kv_div (self-attention: n_q ==
+    // n_tok, kv_div == 1)
+    const int fkv = f / kv_div;
+    const svd_bf16* Qf = Q + (int64_t)f * n_q * ldq + h * 64;
+    const svd_bf16* Kf = K + (int64_t)fkv * n_tok * ldk + h * 64;
+    const svd_bf16* Vf = Vt + ((int64_t)fkv * heads + h) * 64 * tok_ld;
 
     // Q fragments (B operand): lane -> query l31, d = 16*ks + 8*hi .. +8
     int qrow = qb * BQ + wave * 32 + l31;
-    const bool q_valid = qrow < n_tok;
-    if (!q_valid) qrow = n_tok - 1;
+    const bool q_valid = qrow < n_q;
+    if (!q_valid) qrow = n_q - 1;
     uint4 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(Qf + (int64_t)qrow * ldq + 16 * ks + 8 * hi);
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     if (q_valid) {
-        svd_bf16* Orow = O + ((int64_t)f * n_tok + qrow) * ldo + h * 64;
+        svd_bf16* Orow = O + ((int64_t)f * n_q + qrow) * ldo + h * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -179,19 +182,20 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
 // happen.  One half-wave (32 lanes) per (batch, pixel, head): lane i holds query i in fp32 registers; K and V of
 // the problem sit in LDS (bf16) and are read as wave-broadcast 16-byte vectors.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int TA_MAXT = 32;
-template <class E>
+// TA_MAXT = 32: one half-wave per problem (8 per workgroup); TA_MAXT = 64 (the I2VGen-XL enhancer's 38-frame chunks): one wave.
+template <class E, int TA_MAXT>
 __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ V, int64_t ldv, svd_bf16* __restrict__ O, int64_t ldo,
     int batch, int tq, int tk, int n_pix, int heads, int64_t n_prob) {
-    __shared__ __attribute__((aligned(16))) uint16_t sKV[8][2][TA_MAXT][64];   // 64 KiB
+    constexpr int NG = 256 / TA_MAXT;   // problems per workgroup
+    __shared__ __attribute__((aligned(16))) uint16_t sKV[NG][2][TA_MAXT][64];   // 64 KiB
     const int tid = threadIdx.x;
-    const int hw = tid >> 5;            // half-wave 0..7
-    const int li = tid & 31;
+    const int hw = tid / TA_MAXT;       // lane group (half-wave or wave) = problem slot
+    const int li = tid % TA_MAXT;
     const float c = 0.125f;
 
-    for (int64_t base = (int64_t)blockIdx.x * 8; base < n_prob; base += (int64_t)gridDim.x * 8) {
+    for (int64_t base = (int64_t)blockIdx.x * NG; base < n_prob; base += (int64_t)gridDim.x * NG) {
         const int64_t prob = base + hw;
         const bool active = prob < n_prob;
         // problem index -> (b, p, h) with h fastest: the 8 half-waves of a block read adjacent channels/pixels
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
         __syncthreads();   // previous iteration's LDS reads done
         if (active) {
             // stage K,V: tk rows x 128 B each = tk*8 16-byte vectors per matrix, spread over the 32 lanes
-            for (int v = li; v < tk * 8; v += 32) {
+            for (int v = li; v < tk * 8; v += TA_MAXT) {
                 const int j = v >> 3, sl = v & 7;
                 const int64_t row = ((int64_t)b * tk + j) * n_pix + pp;
                 *(uint4*)&sKV[hw][0][j][sl * 8] = *(const uint4*)(K + row * ldk + h * 64 + sl * 8);
@@ -337,21 +341,30 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
-                                    const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
-                                    int32_t frames, int32_t n_tok, int32_t heads, int32_t dtype, svd_stream_t stream) {
-    if (!Q || !K || !Vt || !O || frames <= 0 || n_tok <= 0 || heads <= 0) return SVD_EINVAL;
+extern "C" int svd_attn_cross_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
+                                  const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
+                                  int32_t frames, int32_t n_q, int32_t n_k, int32_t frames_per_kv, int32_t heads,
+                                  int32_t dtype, svd_stream_t stream) {
+    if (!Q || !K || !Vt || !O || frames <= 0 || n_q <= 0 || n_k <= 0 || heads <= 0 || frames_per_kv <= 0) return SVD_EINVAL;
+    if (frames % frames_per_kv) return SVD_EINVAL;
     if (ldq % 8 || ldk % 8 || tok_ld % 8 || ldo % 4) return SVD_EINVAL;
-    if (tok_ld < ((n_tok + 63) / 64) * 64) return SVD_EINVAL;   // V^T rows must cover whole 64-key tiles
+    if (tok_ld < ((n_k + 63) / 64) * 64) return SVD_EINVAL;   // V^T rows must cover whole 64-key tiles
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt) & 15) return SVD_EINVAL;
     constexpr int NW = 4;
-    const int qblocks = (n_tok + NW * 32 - 1) / (NW * 32);
+    const int qblocks = (n_q + NW * 32 - 1) / (NW * 32);
     const int64_t nwg = (int64_t)frames * heads * qblocks;
     if (nwg > 0x7fffffff) return SVD_EINVAL;
     SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<NW, E>), dim3((unsigned)nwg), dim3(NW * 64), 4 * 8192,
-                                                 (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_tok, heads, qblocks));
+                                                 (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k,
+                                                 frames_per_kv, heads, qblocks));
     SVD_CHECK_LAUNCH("attn_spatial_d64");
     return SVD_OK;
+}
+
+extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
+                                    const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
+                                    int32_t frames, int32_t n_tok, int32_t heads, int32_t dtype, svd_stream_t stream) {
+    return svd_attn_cross_d64(Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_tok, n_tok, 1, heads, dtype, stream);
 }
 
 extern "C" int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
@@ -359,14 +372,19 @@ extern "C" int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_b
                                      int32_t batch, int32_t tq, int32_t tk, int32_t n_pix, int32_t heads,
                                      int32_t dtype, svd_stream_t stream) {
     if (!Q || !K || !V || !O || batch <= 0 || n_pix <= 0 || heads <= 0) return SVD_EINVAL;
-    if (tq <= 0 || tk <= 0 || tq > TA_MAXT || tk > TA_MAXT) return SVD_EINVAL;
+    if (tq <= 0 || tk <= 0 || tq > 64 || tk > 64) return SVD_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return SVD_EINVAL;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return SVD_EINVAL;
     const int64_t n_prob = (int64_t)batch * n_pix * heads;
-    int64_t blocks = (n_prob + 7) / 8;
+    const bool small = tq <= 32 && tk <= 32;
+    int64_t blocks = small ? (n_prob + 7) / 8 : (n_prob + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(attn_temporal_d64_kernel<E>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                                 Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
+    if (small)
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_d64_kernel<E, 32>), dim3((unsigned)blocks), dim3(256), 0,
+                                                     (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
+    else
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_d64_kernel<E, 64>), dim3((unsigned)blocks), dim3(256), 0,
+                                                     (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
     SVD_CHECK_LAUNCH("attn_temporal_d64");
     return SVD_OK;
 }

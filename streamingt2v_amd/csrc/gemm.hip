@@ -8,7 +8,7 @@ namespace {
 
 template <class CFG>
 void info(int* bm, int* bn, int* thr, int* lds) {
-    if (bm) *bm = CFG::BM; if (bn) *bn = CFG::BN; if (thr) *thr = CFG::NT; if (lds) *lds = CFG::LAUNCH_LDS;
+    if (bm) *bm = CFG::BM; if (bn) *bn = CFG::BN; if (thr) *thr = CFG::THREADS; if (lds) *lds = CFG::TOTAL_LDS;
 }
 
 // can config `cfg` run these arguments?  (tile-shape independent checks live in svd_gemm)

@@ -5,13 +5,16 @@
 namespace svd_gemm_detail {
 
 
-template <int BM_, int BN_, int WM_, int WN_, int BK_, bool GLDS_, bool TRANS_, int NS_ = 2, bool DELAY_ = false>
+template <int BM_, int BN_, int WM_, int WN_, int BK_, bool GLDS_, bool TRANS_, int NS_ = 2, bool DELAY_ = false, bool PP_ = false>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
     static constexpr bool GLDS = GLDS_, TRANS = TRANS_;
-    static constexpr int NT = WM * WN * 64;
+    static constexpr int NT = WM * WN * 64;        // threads of one wave GROUP (= the workgroup unless ping-pong)
+    static constexpr bool PINGPONG = PP_ && !TRANS_;
+    static constexpr int GROUPS = PINGPONG ? 2 : 1;  // ping-pong: two independent wave groups per workgroup, half an iteration apart
+    static constexpr int THREADS = NT * GROUPS;
     // register budget: 4-wave workgroups with <= 64 accumulator registers per lane must fit twice per SIMD (2 WG / CU)
-    static constexpr int MIN_WAVES_PER_SIMD = (WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? 2 : 1;
+    static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? 2 : 1;
     static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     static constexpr int ROWB = BK * 2;       // bytes per LDS row
     static constexpr int SLOTS = BK / 8;      // 16-byte slots per row
@@ -35,7 +38,8 @@ struct GemmCfg {
     static constexpr int AUX_OFF = LDS_BYTES + (EPI_DEDICATED ? WM * WN * EPI_WAVE_BYTES : 0);
     static constexpr int AUX_SLOTS = NSTAGE + (DELAYED_EPI ? 1 : 0);   // one per tile the load stream can be ahead (+1: the delayed tile)
     static constexpr int LAUNCH_LDS = AUX_OFF + (TRANS_ ? 0 : AUX_SLOTS * AUX_SLOT_BYTES);
-    static_assert(LAUNCH_LDS <= 160 * 1024, "tile configuration exceeds the 160 KiB LDS of a CU");
+    static constexpr int TOTAL_LDS = GROUPS * LAUNCH_LDS;            // LAUNCH_LDS: bytes of ONE group
+    static_assert(TOTAL_LDS <= 160 * 1024, "tile configuration exceeds the 160 KiB LDS of a CU");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of rows-per-pass");
     static_assert(RPP % 16 == 0, "swizzle assumes pass stride multiple of 16 rows");
 };
@@ -62,14 +66,12 @@ struct GemmCfg {
     X(16, 128, 192, 2, 2, 64, true, false, 2) /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */ \
     X(17, 256, 256, 4, 2, 32, true, false, 3) /* 3-stage ring, BK 32: loads 2 K tiles ahead (133 KB)          */ \
     X(18, 256, 128, 4, 2, 64, true, false, 3) /* 3-stage ring (144 KB)                                        */ \
-    X(19, 256, 128, 4, 2, 64, true, false, 12) /* delayed epilogue (stores of tile t inside the K loop of t+1)   */ \
-    X(20, 128, 128, 2, 2, 64, true, false, 12) /* delayed epilogue, 4 waves                                      */ \
-    X(21, 128, 128, 2, 2, 32, true, false, 12) /* delayed epilogue, BK 32 (2 WG/CU)                              */ \
-    X(22, 256, 128, 4, 2, 32, true, false, 12) /* delayed epilogue, BK 32, 8 waves                               */
+    X(19, 256, 128, 4, 2, 64, true, false, 12) /* delayed epilogue: stores of tile t inside the K loop of t+1 (kept: measured, never fastest) */ \
+    X(20, 128, 256, 2, 2, 32, true, false, 22) /* ping-pong: 2 groups x (4 waves, 64x128 per wave), BK 32 (kept: measured, never fastest)   */
 #endif
-constexpr int kNumCfg = 22;
+constexpr int kNumCfg = 20;
 
-#define X(id, bm, bn, wm, wn, bk, glds, tr, ns) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr, (ns) % 10, ((ns) >= 10)>;   /* ns >= 10: delayed epilogue */
+#define X(id, bm, bn, wm, wn, bk, glds, tr, ns) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr, (ns) % 10, (((ns) / 10) & 1) != 0, (((ns) / 10) & 2) != 0>;   /* tens digit: 1 = delayed epilogue, 2 = ping-pong */
 SVD_GEMM_CONFIGS(X)
 #undef X
 

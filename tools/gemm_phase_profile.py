@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from streamingt2v_amd import ops, lib as L
 st=C.c_void_p(torch.cuda.current_stream().cuda_stream)
 M=460800
-for (N,K,flags,res,cfgs) in [(2560,320,1,0,(8,1,5,2,19,20,21,22)),(320,320,0,1,(8,1,5,2,19,20,21,22)),(1280,1280,0,0,(8,1,2,19,21)),(320,2880,0,0,(8,2,19,22))]:
+for (N,K,flags,res,cfgs) in [(2560,320,1,0,(8,1,2,19,20)),(320,320,0,1,(8,1,2,19,20)),(1280,1280,0,0,(8,1,2,19,20)),(320,2880,0,0,(8,2,19,20)),(1280,5120,0,1,(8,1,2,19,20))]:
     a=torch.randn(M,K,device="cuda").to(torch.bfloat16); w=(torch.randn(N,K,device="cuda")*K**-0.5).to(torch.bfloat16)
     bias=torch.randn(N,device="cuda"); nout=N//2 if flags&1 else N
     out=torch.empty(M,nout,device="cuda",dtype=torch.bfloat16); R=torch.randn(M,nout,device="cuda").to(torch.bfloat16) if res else None

@@ -32,6 +32,7 @@ class Tuner:
         key = ops.gemm_signature(args)
         hit = self.table.get(key)
         if hit is not None:
+            hit["calls"] += 1
             return hit["cfg"]
         res = {}
         flops = 2.0 * args.M * args.N * args.K
@@ -52,7 +53,7 @@ class Tuner:
             res[cfg] = best
         cfg = min(res, key=res.get)
         heur = L.lib.svd_gemm_pick_config(C.byref(args))
-        self.table[key] = {"cfg": cfg, "ms": round(res[cfg], 4), "tflops": round(flops / res[cfg] / 1e9, 1),
+        self.table[key] = {"cfg": cfg, "calls": 1, "ms": round(res[cfg], 4), "tflops": round(flops / res[cfg] / 1e9, 1),
                            "heuristic_cfg": heur, "heuristic_ms": round(res.get(heur, float("nan")), 4),
                            "all_ms": {str(k): round(v, 4) for k, v in sorted(res.items())}}
         args.tile_cfg = 0
@@ -85,6 +86,11 @@ def main():
         json.dump({"device": torch.cuda.get_device_name(0), "note": "best tile config per GEMM signature, tools/tune_gemm.py",
                    "table": dict(sorted(tuner.table.items()))}, f, indent=0)
     print(f"wrote {out}: {len(tuner.table)} signatures; summed per-signature gain over heuristic {gain:.1f} ms")
+    rank = sorted(tuner.table.items(), key=lambda kv: -kv[1]["calls"] * kv[1]["ms"])
+    tot = sum(v["calls"] * v["ms"] for v in tuner.table.values())
+    print(f"GEMM time of the two tuned forwards + decode: {tot:.1f} ms; top signatures (calls x ms):")
+    for k, v in rank[:45]:
+        print(f"  {v['calls'] * v['ms']:8.2f} ms  {v['calls']:4d} x {v['ms']:7.3f}  cfg{v['cfg']:<3d} {v['tflops']:6.0f} TF  {k}")
     if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
         import shutil
         shutil.copy(out, os.path.join(ROOT, "gpurun_out", "gemm_tiles.json"))
