@@ -51,7 +51,7 @@ const char* svd_last_error(void);
  * A_view modes (implicit GEMM, nothing is materialised):
  *   SVD_A_PLAIN    : row m of A, K contiguous.
  *   SVD_A_CONV3X3  : m = (f, yo, xo); K = 9*cin ordered (ky, kx, c); zero padding 1; stride 1|2; optional
- *                    nearest 2x upsample of the source (ups=1) folded into the addressing.
+ *                    nearest 2x upsample of the source (ups=1; hout in {2 hin - 1, 2 hin}) folded into the addressing.
  *   SVD_A_TEMPORAL3: m = (b, t, p); K = 3*cin ordered (kt, c); zero padding at t=0 and t=T-1.
  * Epilogue, in this order (each optional):  v = acc + bias[n] + rowvec[m / rows_per_vec][n] + R[m][n];
  *   GEGLU (W rows interleaved in blocks of 32: value|gate): v = v_value * gelu_erf(v_gate), N_out = N/2;
@@ -115,7 +115,19 @@ int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int6
                          const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
                          int32_t frames, int32_t n_tok, int32_t heads, int32_t dtype, svd_stream_t stream);
 
-/* Per-pixel temporal attention over short sequences (<= 32), head dim 64.
+/* Cross-attention form of the kernel above: n_q queries per frame attend to the n_k keys/values of key-value set
+ * (frame / frames_per_kv) -- K rows [(frames/frames_per_kv) * n_k], Vt [frames/frames_per_kv][heads*64][tok_ld >= 64-multiple of n_k].
+ * Replaces attn2 of the enhancer's Transformer2DModel blocks (code/i2v_enhance/attention.py:488-501: 77 text + 64 image-latent
+ * + 4 CLIP tokens, shared by all frames of a batch element, unet_i2vgen_xl.py:664-690) -- diffusers AttnProcessor2_0 SDPA.
+ * svd_attn_spatial_d64 == svd_attn_cross_d64 with n_q == n_k, frames_per_kv == 1. */
+int svd_attn_cross_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_t ldk,
+                       const svd_bf16* Vt, int64_t tok_ld, svd_bf16* O, int64_t ldo,
+                       int32_t frames, int32_t n_q, int32_t n_k, int32_t frames_per_kv, int32_t heads,
+                       int32_t dtype, svd_stream_t stream);
+
+/* Per-pixel temporal attention over short sequences (<= 64; <= 32 uses half-waves), head dim 64.
+ * Also the two self-attentions of the enhancer's TransformerTemporalModel (code/i2v_enhance/transformer_temporal.py:160-195,
+ * 38-frame chunks).
  * Replaces the attention inside VideoTransformerBlock.attn1 (models/svd/sgm/modules/video_attention.py:145-148,
  * on the "(b t) s c -> (b s) t c" view, never materialised here) and the diffusers Attention of the CAM
  * merger (models/cam/conditioning.py:65-68; q 25 frames, kv 7 ControlNet frames).
@@ -192,6 +204,21 @@ int svd_edm_euler_step(float* x, const float* net, int64_t ldn, const float* gui
  */
 int svd_ae_time_mix3(const float* X, int64_t ldx, const float* w /*[3][3][3] (co,ci,kt)*/, const float* b,
                      float* Y, int32_t frames, int32_t pix, int32_t clamp, svd_stream_t stream);
+
+/* ---- I2VGen-XL enhancement stage ------------------------------------------------------ */
+/* nn.AdaptiveAvgPool2d((hout, wout)) on channels-last tokens (image_latents_context_embedding[2],
+ * code/i2v_enhance/unet_i2vgen_xl.py:262-269). */
+int svd_adaptive_avgpool_tokens(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t hin,
+                                int32_t win, int32_t hout, int32_t wout, int32_t channels, int32_t dtype, svd_stream_t stream);
+/* I2VGenXLTransformerTemporalEncoder on the 4-channel image latents (unet_i2vgen_xl.py:110-160, call site :700-709):
+ * X rows (b, f, p) with >= 4 channels; params = ln_w[4] ln_b[4] wq[8][4] wk[8][4] wv[8][4] wo[4][8] bo[4] w1[16][4] b1[16]
+ * w2[4][16] b2[4] (288 floats); Y fp32 NCHW [(b f), 4, pix].  frames <= 64. */
+int svd_i2v_image_temporal_encoder(const svd_bf16* X, int64_t ldx, const float* params, float* Y, int32_t batch,
+                                   int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream);
+/* Classifier-free guidance + one DDIM step (eta 0) on fp32 latents (pipeline_i2vgen_xl.py:872-885 + diffusers
+ * DDIMScheduler.step): v = pu + g (pc - pu) (pc may be NULL: no guidance); out = sqrt(a_prev) x0 + sqrt(1 - a_prev) eps. */
+int svd_ddim_cfg_step(const float* x, const float* pred_uncond, const float* pred_cond, float* out, int64_t n,
+                      float guidance_scale, float alpha_t, float alpha_prev, int32_t v_prediction, svd_stream_t stream);
 
 #ifdef __cplusplus
 }

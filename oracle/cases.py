@@ -76,7 +76,7 @@ def tiny_vae_inputs():
 # upsample size (the shipped 90x160 latent does too: 90 % 8 != 0).
 TINY_I2V = dict(block_out_channels=(64, 128, 128), down_block_types=("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
                 up_block_types=("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"), layers_per_block=1,
-                norm_num_groups=32, cross_attention_dim=128, attention_head_dim=64, F=6, h=9, w=12, text_tokens=7)
+                norm_num_groups=32, cross_attention_dim=128, attention_head_dim=64, F=6, h=9, w=16, text_tokens=7)
 
 
 def tiny_i2v_kwargs():

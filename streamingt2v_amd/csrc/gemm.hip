@@ -69,6 +69,8 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
             if (a.K != 9 * a.cin || a.hin <= 0 || a.win <= 0 || a.hout <= 0 || a.wout <= 0) return SVD_EINVAL;
             if ((a.stride != 1 && a.stride != 2) || (a.ups != 0 && a.ups != 1)) return SVD_EINVAL;
             if (a.M % (a.hout * a.wout) != 0) return SVD_EINVAL;
+            if (a.ups && (a.stride != 1 || a.hout > 2 * a.hin || a.hout < 2 * a.hin - 1 || a.wout > 2 * a.win || a.wout < 2 * a.win - 1))
+                return SVD_EINVAL;
         } else if (a.a_mode == SVD_A_TEMPORAL3) {
             if (a.K != 3 * a.cin || a.t_frames <= 0 || a.rows_per_frame <= 0) return SVD_EINVAL;
             if (a.M % (a.t_frames * a.rows_per_frame) != 0) return SVD_EINVAL;

@@ -1,0 +1,101 @@
+"""Enhancement stage: SDEdit denoising with the I2VGen-XL UNet and randomized blending (call stack §3.5).
+
+Mirrors the denoising loop of the reference's ``I2VGenXLPipeline.__call__`` (code/i2v_enhance/pipeline_i2vgen_xl.py:812-913):
+
+    scheduler.set_timesteps(30); timesteps = timesteps[t_start:]   (strength 0.97 -> 29 steps)            :812-816, 541-551
+    latents = add_noise(video_latents, noise, timesteps[0])                                               :605-613
+    for t in timesteps:
+        for idx, window in chunks(latents, chunk_size, overlap):       # independent given `latents`      :846
+            pred = unet(cat[window] * 2, t, text, fps, image_latents[idx], image_embeddings[idx])        :851-867
+            pred = uncond + guidance_scale * (text - uncond)                                              :870-874
+            window = scheduler.step(pred, t, window)                                                      :884-885
+            latents_denoised[:, :, start + r : start + chunk] = window[:, :, r:]      r random            :891-903
+        latents = latents_denoised
+
+The UNet forward, the guidance and the DDIM update run in libsvdhip.so (i2vgen_unet.py, svd_ddim_cfg_step); the window
+bookkeeping is blending.py (single device) or its rank-sharded form.  What is NOT here: the CLIP text /
+image encoders and the 2-D AutoencoderKL that produce ``prompt_embeds``, ``image_embeddings``, ``image_latents`` and the
+video latents -- the caller passes those tensors, exactly the arguments the reference's loop consumes.
+"""
+import random
+
+import torch
+
+from . import blending, ops
+
+
+class DDIMSchedule:
+    """The subset of diffusers==0.30.2 DDIMScheduler the loop uses (set_timesteps 'leading' + steps_offset, add_noise, step with
+    eta 0), configured like ali-vilab/i2vgen-xl's scheduler_config.json as far as it is known offline: scaled_linear betas
+    0.00085..0.012, 1000 train steps, v_prediction, rescale_betas_zero_snr, steps_offset 1, set_alpha_to_one False.  Host-side
+    fp64 table math; the per-element update is the HIP kernel.  (diffusers is not vendored: parity unpinned, see oracle header.)"""
+
+    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, prediction_type="v_prediction",
+                 rescale_betas_zero_snr=True, set_alpha_to_one=False):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+        if rescale_betas_zero_snr:
+            ac = torch.cumprod(1.0 - betas, 0).sqrt()
+            a0, aT = ac[0].clone(), ac[-1].clone()
+            ac = (ac - aT) * a0 / (a0 - aT)
+            ab = ac ** 2
+            betas = 1 - torch.cat([ab[0:1], ab[1:] / ab[:-1]])
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, 0)
+        self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(self.alphas_cumprod[0])
+        self.num_train, self.offset, self.v_prediction = num_train, steps_offset, prediction_type == "v_prediction"
+
+    def set_timesteps(self, n):
+        self.n = n
+        self.timesteps = [int(i * (self.num_train // n)) + self.offset for i in range(n)][::-1]
+        return self.timesteps
+
+    def get_timesteps(self, n, strength):
+        """pipeline_i2vgen_xl.py:541-551 (img2img): drop the first n - int(n * strength) steps."""
+        self.set_timesteps(n)
+        t_start = max(n - min(int(n * strength), n), 0)
+        return self.timesteps[t_start:]
+
+    def alphas(self, t):
+        prev = t - self.num_train // self.n
+        return float(self.alphas_cumprod[t]), (float(self.alphas_cumprod[prev]) if prev >= 0 else self.final_alpha_cumprod)
+
+    def add_noise(self, x0, noise, t):
+        a = float(self.alphas_cumprod[t])
+        return a ** 0.5 * x0 + (1 - a) ** 0.5 * noise
+
+
+class I2VEnhancer:
+    """unet: streamingt2v_amd.i2vgen_unet.I2VGenXLUNet (weights loaded).  One instance per process / GPU."""
+
+    def __init__(self, unet, scheduler=None, guidance_scale=9.0, num_inference_steps=30, strength=0.97):
+        self.unet, self.sched = unet, scheduler or DDIMSchedule()
+        self.g, self.steps, self.strength = guidance_scale, num_inference_steps, strength
+        self._consts = {}
+
+    def _denoise_window(self, window, t, cond):
+        """window fp32 [1, 4, chunk, h, w] -> DDIM-updated window.  cond = dict(fps [2], image_latents [2,4,chunk,h,w],
+        image_embeddings [2,cd], text [2,77,cd]) with the unconditional half first (pipeline order, :770-796)."""
+        _, C, Fr, H, W = window.shape
+        const = self._consts.get(id(cond))
+        if const is None:        # once per window: constant over the DDIM steps (the reference recomputes it in every forward)
+            const = self._consts[id(cond)] = self.unet.set_conditioning(cond["fps"], cond["image_latents"], cond["image_embeddings"],
+                                                                      cond["text"])
+        self.unet.use_conditioning(const)
+        fr = window[0].permute(1, 0, 2, 3).contiguous()                      # [chunk, 4, h, w]
+        pred = self.unet.forward_frames(torch.cat([fr, fr], 0), t)            # [(2 chunk), 4, h, w]: uncond | text
+        a_t, a_prev = self.sched.alphas(t)
+        out = ops.ddim_cfg_step(fr, pred[:Fr].contiguous(), pred[Fr:].contiguous(), self.g, a_t, a_prev, self.sched.v_prediction)
+        return out.permute(1, 0, 2, 3)[None]
+
+    def denoise(self, video_latents, noise, conds, chunk_size, overlap_size, rng=random, group=None):
+        """video_latents / noise fp32 [1, 4, F, h, w]; conds: one dict per window.  Returns the enhanced latents."""
+        ts = self.sched.get_timesteps(self.steps, self.strength)
+        self._consts = {}
+        latents = self.sched.add_noise(video_latents, noise, ts[0])
+        n_chunks = len(conds)
+        for t in ts:
+            fn = lambda idx, w, t=t: self._denoise_window(w, t, conds[idx])
+            if group is None:
+                latents = blending.blend_step(latents, fn, chunk_size, overlap_size, n_chunks, rng)
+            else:
+                latents = blending.blend_step_sharded(latents, fn, chunk_size, overlap_size, n_chunks, rng, group)
+        return latents

@@ -290,3 +290,44 @@ def ae_time_mix3(x, w, b, frames, h, wd, clamp):
     check(_lib.svd_ae_time_mix3(_p(x), x.stride(0), _p(w), _p(b), _p(out), frames, h * wd, int(clamp), _stream()),
           "svd_ae_time_mix3")
     return out
+
+
+# ---- I2VGen-XL enhancement stage (row A12) ---------------------------------------------------------------------------
+def attn_cross(q, k, vt, out, frames, n_q, n_k, frames_per_kv, heads):
+    """q: view at head 0 of [frames*n_q, ld]; k: [(frames/frames_per_kv)*n_k, ld]; vt: [frames/frames_per_kv, heads*64, tok_ld]."""
+    args = (_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out), out.stride(0), frames, n_q, n_k,
+            frames_per_kv, heads, _dt(q), _stream())
+    if trace is not None:
+        with trace.launch("attn_cross_d64", flops=4.0 * frames * heads * n_q * n_k * 64):
+            check(_lib.svd_attn_cross_d64(*args), "svd_attn_cross_d64")
+        return out
+    check(_lib.svd_attn_cross_d64(*args), "svd_attn_cross_d64")
+    return out
+
+
+def adaptive_avgpool(x, frames, hin, win, hout, wout):
+    Cc = x.shape[1]
+    out = torch.empty((frames * hout * wout, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.svd_adaptive_avgpool_tokens(_p(x), x.stride(0), _p(out), out.stride(0), frames, hin, win, hout, wout, Cc, _dt(x),
+                                           _stream()), "svd_adaptive_avgpool_tokens")
+    return out
+
+
+def i2v_image_temporal_encoder(x, params, batch, frames, h, w):
+    """x [(b f) h w, >=4] tokens -> fp32 [(b f), 4, h, w]."""
+    assert params.dtype == torch.float32 and params.numel() == 288 and params.is_contiguous()
+    out = torch.empty((batch * frames, 4, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.svd_i2v_image_temporal_encoder(_p(x), x.stride(0), _p(params), _p(out), batch, frames, h * w, _dt(x), _stream()),
+          "svd_i2v_image_temporal_encoder")
+    return out
+
+
+def ddim_cfg_step(x, pred_uncond, pred_cond, guidance_scale, alpha_t, alpha_prev, v_prediction=True, out=None):
+    """fp32 tensors of equal shape (contiguous); returns x_prev (diffusers DDIMScheduler.step, eta 0, after CFG)."""
+    for t in (x, pred_uncond) + ((pred_cond,) if pred_cond is not None else ()):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == x.numel()
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.svd_ddim_cfg_step(_p(x), _p(pred_uncond), _p(pred_cond), _p(out), x.numel(), float(guidance_scale), float(alpha_t),
+                                 float(alpha_prev), int(v_prediction), _stream()), "svd_ddim_cfg_step")
+    return out

@@ -74,3 +74,38 @@ def test_sampler_oracle_matches_reference(golden_dir):
     net = lambda a, cn_, cc: O.streaming_wrapper(sd_u, sd_c, ocfg, a, cn_, cc, 2, tu["T"], tu["Tc"], inp["ctrl_frames"])
     z = O.euler_edm_sample(net, sin["noise"].clone(), sin["c"], sin["uc"], 2, tu["T"])
     assert (z - gold["z"]).abs().max().item() <= 5 * TOL
+
+
+# ---- enhancement stage (row A12) ---------------------------------------------------------------------------------------
+def test_i2v_oracle_matches_vendored_reference(golden_dir):
+    """oracle/i2vgen_oracle.py vs the output of the reference's unmodified vendored I2VGenXLUNet (tests/golden/i2v_tiny.pt)."""
+    torch.set_grad_enabled(False)
+    from oracle import i2vgen_oracle as OI
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from streamingt2v_amd.params import init_by_name
+    kw = cases.tiny_i2v_kwargs()
+    spec = I2VGenXLUNet(I2VConfig(block_out_channels=kw["block_out_channels"], layers_per_block=kw["layers_per_block"],
+                                  cross_attention_dim=kw["cross_attention_dim"], attn_levels=(True, True, False))).spec()
+    sd = init_by_name(spec, seed=5)
+    inp = cases.tiny_i2v_inputs()
+    out = OI.unet(sd, inp["sample"], inp["t"], inp["fps"], inp["image_latents"], inp["image_embeddings"], inp["text"])
+    gold = torch.load(os.path.join(golden_dir, "i2v_tiny.pt"))["out"]
+    assert (out - gold).abs().max().item() <= TOL
+
+
+def test_ddim_schedule_properties():
+    """DDIM restatement: zero terminal SNR, 'leading' timesteps with offset 1, step() inverts add_noise for an exact prediction."""
+    from oracle.i2vgen_oracle import DDIM
+    d = DDIM()
+    assert abs(d.alphas_cumprod[-1].item()) < 1e-10 and abs(d.alphas_cumprod[0].item() - 0.99915) < 1e-4
+    d.set_timesteps(30)
+    assert d.timesteps.tolist()[:3] == [958, 925, 892] and d.timesteps[-1].item() == 1
+    g = torch.Generator(); g.manual_seed(1)
+    x0, eps = torch.randn(2, 4, 3, 3, generator=g), torch.randn(2, 4, 3, 3, generator=g)
+    t = 496
+    a = d.alphas_cumprod[t]
+    xt = d.add_noise(x0, eps, t)
+    v = a.sqrt() * eps - (1 - a).sqrt() * x0                  # exact v-prediction
+    prev = d.step(v, t, xt)
+    a_prev = d.alphas_cumprod[t - 33]
+    assert torch.allclose(prev, a_prev.sqrt() * x0 + (1 - a_prev).sqrt() * eps, atol=1e-5)
