@@ -80,6 +80,20 @@ def main():
         print(f"{workload}: {len(tuner.table)} signatures after {time.time() - t0:.0f}s", flush=True)
         del wrapper, vae, model
         torch.cuda.empty_cache()
+    # enhancement stage: one I2VGen-XL UNet forward of a 38-frame window (CFG batch 2) at latent 90x160
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from streamingt2v_amd.params import init_by_name
+    unet = I2VGenXLUNet(I2VConfig())
+    unet.load_state_dict(init_by_name(unet.spec(), seed=5, device=dev), device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    rn = lambda *sh: torch.randn(*sh, generator=g, device=dev)
+    with torch.no_grad():
+        unet(rn(2, 4, 38, 90, 160), 500, fps=torch.tensor([16, 16]), image_latents=rn(2, 4, 38, 90, 160), image_embeddings=rn(2, 1024),
+             encoder_hidden_states=rn(2, 77, 1024))
+    torch.cuda.synchronize()
+    print(f"enhance: {len(tuner.table)} signatures after {time.time() - t0:.0f}s", flush=True)
+    del unet
+    torch.cuda.empty_cache()
     out = os.path.join(ROOT, "streamingt2v_amd", "gemm_tiles.json")
     gain = sum(v["heuristic_ms"] - v["ms"] for v in tuner.table.values() if v["heuristic_ms"] == v["heuristic_ms"])
     with open(out, "w") as f:
