@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvdhip_probe.so" if os.environ.get("SVD_LIB") == "probe" else "libsvdhip.so")   # probe: developer build with a reduced tile table
+LIB_PATH = os.path.join(_HERE, {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""), "libsvdhip.so"))   # probe: developer build with a reduced tile table
 
 ABI_VERSION = 2
 

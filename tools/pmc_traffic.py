@@ -14,7 +14,7 @@ def per_kernel(db, counter):
 
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("svd_gemm_detail::", "")
-    m = re.search(r"gemm_kernel<GemmCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \w+, (\w+)>, (\d), Elem(\w+)>", n)
+    m = re.search(r"gemm_kernel<GemmCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \w+, (\w+)(?:, [^>]*)?>, (\d), Elem(\w+)>", n)
     if m:
         return f"gemm {m.group(1)}x{m.group(2)} bk{m.group(5)} mode{m.group(7)}{' T' if m.group(6) == 'true' else ''} {m.group(8).lower()}"
     return re.sub(r"^void ", "", n).split("(")[0]
