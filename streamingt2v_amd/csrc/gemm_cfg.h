@@ -14,7 +14,7 @@ struct GemmCfg {
     static constexpr int GROUPS = PINGPONG ? 2 : 1;  // ping-pong: two independent wave groups per workgroup, half an iteration apart
     static constexpr int THREADS = NT * GROUPS;
     // register budget: 4-wave workgroups with <= 64 accumulator registers per lane must fit twice per SIMD (2 WG / CU)
-    static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? 2 : 1;
+    static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && WM * WN == 4 && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64 || BK_ == 32)) ? 2 : 1;   // BK 32 + 128 accumulators: 2 x 58 KB LDS, 256 registers
     static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     static constexpr int ROWB = BK * 2;       // bytes per LDS row
     static constexpr int SLOTS = BK / 8;      // 16-byte slots per row
