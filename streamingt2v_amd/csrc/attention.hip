@@ -1,5 +1,6 @@
 // Attention kernels for gfx950 (head dim 64 everywhere in the StreamingSVD UNet / ControlNet / CAM).
 #include "svd_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -15,7 +16,7 @@ namespace {
 // K and V^T tiles are staged with global_load_lds; swizzle (slot ^= (row>>1)&7) on source address and on read.
 // ------------------------------------------------------------------------------------------------------------
 template <int NW, class E>
-__global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
+__global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ Vt, int64_t tok_ld, svd_bf16* __restrict__ O, int64_t ldo,
     int frames, int n_q, int n_tok /* keys */, int kv_div, int heads, int qblocks) {
@@ -125,21 +126,33 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_d64_kernel(
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * c);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        // lazy rescale: once the running maximum has settled (after the first few KV tiles for typical scores) alpha is exactly
+        // 1 in every lane; the wave-uniform test skips the 32 accumulator multiplies of the tile
+        const bool rescale = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;
         m_run = m_new;
-        float psum = 0.f;
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): the softmax is VALU-bound (32 exp2 + ~110 other VALU ops per tile
+        // against 16 MFMAs), so two scores per instruction where the ISA has it
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 c2 = {c, c}, m2 = {-m_new, -m_new};
+        f32x2 ps2 = {0.f, 0.f};
         uint32_t pk[2][8];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(s_acc[kb][r] * c - m_new);
-                const float p1 = __builtin_amdgcn_exp2f(s_acc[kb][r + 1] * c - m_new);
-                psum += p0 + p1;
-                pk[kb][r >> 1] = E::pack(p0, p1);
+                const f32x2 sv = {s_acc[kb][r], s_acc[kb][r + 1]};
+                const f32x2 e = __builtin_elementwise_fma(sv, c2, m2);
+                f32x2 pv;
+                pv[0] = __builtin_amdgcn_exp2f(e[0]);
+                pv[1] = __builtin_amdgcn_exp2f(e[1]);
+                ps2 += pv;
+                pk[kb][r >> 1] = E::pack(pv[0], pv[1]);
             }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (ps2[0] + ps2[1]);
+        if (rescale) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o_acc[0][i] *= alpha; o_acc[1][i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o_acc[0][i] *= alpha; o_acc[1][i] *= alpha; }
+        }
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -350,13 +363,22 @@ extern "C" int svd_attn_cross_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16
     if (ldq % 8 || ldk % 8 || tok_ld % 8 || ldo % 4) return SVD_EINVAL;
     if (tok_ld < ((n_k + 63) / 64) * 64) return SVD_EINVAL;   // V^T rows must cover whole 64-key tiles
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt) & 15) return SVD_EINVAL;
-    constexpr int NW = 4;
-    const int qblocks = (n_q + NW * 32 - 1) / (NW * 32);
+    // 8 waves (256 queries) per workgroup for long sequences: every workgroup streams ALL keys/values of its (frame, head) through
+    // LDS, so queries per workgroup set the L2 -> LDS traffic per FLOP (4 waves: 128 FLOP/B = 7 TB/s at 900 TFLOP/s, measured to
+    // be the limit); 4 waves for short sequences (more workgroups, less tail).
+    const bool wide = n_q >= 2048 && ((uint64_t)(uintptr_t)getenv("SVD_ATTN_NW4") == 0);
+    const int nw = wide ? 8 : 4;
+    const int qblocks = (n_q + nw * 32 - 1) / (nw * 32);
     const int64_t nwg = (int64_t)frames * heads * qblocks;
     if (nwg > 0x7fffffff) return SVD_EINVAL;
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<NW, E>), dim3((unsigned)nwg), dim3(NW * 64), 4 * 8192,
-                                                 (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k,
-                                                 frames_per_kv, heads, qblocks));
+    if (wide)
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<8, E>), dim3((unsigned)nwg), dim3(8 * 64), 4 * 8192,
+                                                     (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k,
+                                                     frames_per_kv, heads, qblocks));
+    else
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<4, E>), dim3((unsigned)nwg), dim3(4 * 64), 4 * 8192,
+                                                     (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k,
+                                                     frames_per_kv, heads, qblocks));
     SVD_CHECK_LAUNCH("attn_spatial_d64");
     return SVD_OK;
 }
