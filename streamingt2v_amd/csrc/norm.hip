@@ -34,13 +34,20 @@ __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t 
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
     if (rr < R) {
         const svd_bf16* base = X + ((int64_t)f * pix) * ldx + o * 8;
-        for (int r = r0 + rr; r < r1; r += R) {
-            const uint4 u = *(const uint4*)(base + (int64_t)r * ldx);
-            float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y),
-                          E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
+        auto acc8 = [&](const uint4 u) {
+            const float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y), E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
 #pragma unroll
             for (int i = 0; i < 8; ++i) { s[i] += v[i]; ss[i] += v[i] * v[i]; }
+        };
+        int r = r0 + rr;
+        for (; r + 3 * R < r1; r += 4 * R) {          // 4 independent 16-byte loads in flight per thread (HBM-latency bound otherwise)
+            const uint4 u0 = *(const uint4*)(base + (int64_t)r * ldx);
+            const uint4 u1 = *(const uint4*)(base + (int64_t)(r + R) * ldx);
+            const uint4 u2 = *(const uint4*)(base + (int64_t)(r + 2 * R) * ldx);
+            const uint4 u3 = *(const uint4*)(base + (int64_t)(r + 3 * R) * ldx);
+            acc8(u0); acc8(u1); acc8(u2); acc8(u3);
         }
+        for (; r < r1; r += R) acc8(*(const uint4*)(base + (int64_t)r * ldx));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             atomicAdd(&sch[(o * 8 + i) * 2 + 0], s[i]);
@@ -107,10 +114,8 @@ __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd
     }
     const svd_bf16* xb = X + ((int64_t)f * pix) * ldx + o * 8;
     svd_bf16* yb = Y + ((int64_t)f * pix) * ldy + o * 8;
-    for (int r = r0 + rr; r < r1; r += R) {
-        const uint4 u = *(const uint4*)(xb + (int64_t)r * ldx);
-        float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y),
-                      E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
+    auto one = [&](const uint4 u, int r) {
+        float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y), E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             v[i] = v[i] * ca[i] + cb[i];
@@ -120,57 +125,79 @@ __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd
         w.x = E::pack(v[0], v[1]); w.y = E::pack(v[2], v[3]);
         w.z = E::pack(v[4], v[5]); w.w = E::pack(v[6], v[7]);
         *(uint4*)(yb + (int64_t)r * ldy) = w;
+    };
+    int r = r0 + rr;
+    for (; r + 3 * R < r1; r += 4 * R) {              // 4 independent loads in flight per thread
+        const uint4 u0 = *(const uint4*)(xb + (int64_t)r * ldx);
+        const uint4 u1 = *(const uint4*)(xb + (int64_t)(r + R) * ldx);
+        const uint4 u2 = *(const uint4*)(xb + (int64_t)(r + 2 * R) * ldx);
+        const uint4 u3 = *(const uint4*)(xb + (int64_t)(r + 3 * R) * ldx);
+        one(u0, r); one(u1, r + R); one(u2, r + 2 * R); one(u3, r + 3 * R);
     }
+    for (; r < r1; r += R) one(*(const uint4*)(xb + (int64_t)r * ldx), r);
 }
 
-// LayerNorm: one wave per token row; up to MAXV 16-byte vectors per lane (C <= 64*8*MAXV).
+// LayerNorm: one wave per token row, NR rows per wave in flight (the kernel is latency-bound with one 16-byte load per lane
+// per row: 3.6 TB/s measured); up to MAXV 16-byte vectors per lane (C <= 64*8*MAXV).
 template <int MAXV, class E>
 __global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y,
                                                         int64_t ldy, int64_t rows, int channels, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         const float* __restrict__ addvec, int addvec_ld, int rows_per_vec,
                                                         svd_bf16* __restrict__ Xsum, int64_t ldxsum, int silu) {
+    constexpr int NR = (MAXV <= 2) ? 2 : 1;
     const int lane = threadIdx.x & 63;
     const int octets = channels >> 3;
     const float invc = 1.f / (float)channels;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
-        float v[MAXV][8];
-        float sum = 0.f;
-        const svd_bf16* xr = X + row * ldx;
-        const float* av = addvec ? addvec + (row / rows_per_vec) * addvec_ld : nullptr;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row0 = wave_id * NR; row0 < rows; row0 += nwaves * NR) {
+        float v[NR][MAXV][8];
+        float sum[NR];
 #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-            const int o = lane + 64 * k;
-            if (o < octets) {
-                const uint4 u = *(const uint4*)(xr + o * 8);
-                v[k][0] = E::lo(u.x); v[k][1] = E::hi(u.x); v[k][2] = E::lo(u.y); v[k][3] = E::hi(u.y);
-                v[k][4] = E::lo(u.z); v[k][5] = E::hi(u.z); v[k][6] = E::lo(u.w); v[k][7] = E::hi(u.w);
-                if (av) {
-                    const float4 a0 = *(const float4*)(av + o * 8), a1 = *(const float4*)(av + o * 8 + 4);
-                    v[k][0] += a0.x; v[k][1] += a0.y; v[k][2] += a0.z; v[k][3] += a0.w;
-                    v[k][4] += a1.x; v[k][5] += a1.y; v[k][6] += a1.z; v[k][7] += a1.w;
-                    if (Xsum) {
-                        uint4 w;
-                        w.x = E::pack(v[k][0], v[k][1]); w.y = E::pack(v[k][2], v[k][3]);
-                        w.z = E::pack(v[k][4], v[k][5]); w.w = E::pack(v[k][6], v[k][7]);
-                        *(uint4*)(Xsum + row * ldxsum + o * 8) = w;
+        for (int j = 0; j < NR; ++j) {
+            sum[j] = 0.f;
+            int64_t row = row0 + j; if (row > rows - 1) row = rows - 1;            // tail: recompute the last row, store masked below
+            const svd_bf16* xr = X + row * ldx;
+            const float* av = addvec ? addvec + (row / rows_per_vec) * addvec_ld : nullptr;
+#pragma unroll
+            for (int k = 0; k < MAXV; ++k) {
+                const int o = lane + 64 * k;
+                if (o < octets) {
+                    const uint4 u = *(const uint4*)(xr + o * 8);
+                    v[j][k][0] = E::lo(u.x); v[j][k][1] = E::hi(u.x); v[j][k][2] = E::lo(u.y); v[j][k][3] = E::hi(u.y);
+                    v[j][k][4] = E::lo(u.z); v[j][k][5] = E::hi(u.z); v[j][k][6] = E::lo(u.w); v[j][k][7] = E::hi(u.w);
+                    if (av) {
+                        const float4 a0 = *(const float4*)(av + o * 8), a1 = *(const float4*)(av + o * 8 + 4);
+                        v[j][k][0] += a0.x; v[j][k][1] += a0.y; v[j][k][2] += a0.z; v[j][k][3] += a0.w;
+                        v[j][k][4] += a1.x; v[j][k][5] += a1.y; v[j][k][6] += a1.z; v[j][k][7] += a1.w;
+                        if (Xsum && row0 + j < rows) {
+                            uint4 w;
+                            w.x = E::pack(v[j][k][0], v[j][k][1]); w.y = E::pack(v[j][k][2], v[j][k][3]);
+                            w.z = E::pack(v[j][k][4], v[j][k][5]); w.w = E::pack(v[j][k][6], v[j][k][7]);
+                            *(uint4*)(Xsum + row * ldxsum + o * 8) = w;
+                        }
                     }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sum[j] += v[j][k][i];
                 }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sum += v[k][i];
             }
         }
-        const float mean = wave_sum(sum) * invc;
-        float sq = 0.f;
+        float mean[NR], rstd[NR];
 #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-            const int o = lane + 64 * k;
-            if (o < octets) {
+        for (int j = 0; j < NR; ++j) mean[j] = wave_sum(sum[j]) * invc;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; sq += d * d; }
+        for (int j = 0; j < NR; ++j) {
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXV; ++k) {
+                const int o = lane + 64 * k;
+                if (o < octets) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float d = v[j][k][i] - mean[j]; sq += d * d; }
+                }
             }
+            rstd[j] = rsqrtf(wave_sum(sq) * invc + eps);
         }
-        const float rstd = rsqrtf(wave_sum(sq) * invc + eps);
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
             const int o = lane + 64 * k;
@@ -179,16 +206,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restri
                 const float4 b0 = *(const float4*)(beta + o * 8), b1 = *(const float4*)(beta + o * 8 + 4);
                 const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
                 const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                float y[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    y[i] = (v[k][i] - mean) * rstd * gg[i] + bb[i];
-                    if (silu) y[i] = silu_f(y[i]);
+                for (int j = 0; j < NR; ++j) {
+                    if (row0 + j >= rows) continue;
+                    float y[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        y[i] = (v[j][k][i] - mean[j]) * rstd[j] * gg[i] + bb[i];
+                        if (silu) y[i] = silu_f(y[i]);
+                    }
+                    uint4 w;
+                    w.x = E::pack(y[0], y[1]); w.y = E::pack(y[2], y[3]);
+                    w.z = E::pack(y[4], y[5]); w.w = E::pack(y[6], y[7]);
+                    *(uint4*)(Y + (row0 + j) * ldy + o * 8) = w;
                 }
-                uint4 w;
-                w.x = E::pack(y[0], y[1]); w.y = E::pack(y[2], y[3]);
-                w.z = E::pack(y[4], y[5]); w.w = E::pack(y[6], y[7]);
-                *(uint4*)(Y + row * ldy + o * 8) = w;
             }
         }
     }
@@ -250,7 +281,7 @@ extern "C" int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_
     if (addvec && (rows_per_vec <= 0 || addvec_ld % 4)) return SVD_EINVAL;
     if (Xsum && (!addvec || ldxsum % 8)) return SVD_EINVAL;
     if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)addvec | (uintptr_t)Xsum) & 15) return SVD_EINVAL;
-    int64_t blocks = (rows + 3) / 4;
+    int64_t blocks = (rows + 7) / 8;                      // 4 waves x (up to) 2 rows per workgroup pass
     if (blocks > 256 * 32) blocks = 256 * 32;
     const int octets = channels / 8;
 #define LN_LAUNCH(MV)                                                                                                        \
