@@ -220,6 +220,11 @@ int svd_i2v_image_temporal_encoder(const svd_bf16* X, int64_t ldx, const float* 
 int svd_ddim_cfg_step(const float* x, const float* pred_uncond, const float* pred_cond, float* out, int64_t n,
                       float guidance_scale, float alpha_t, float alpha_prev, int32_t v_prediction, svd_stream_t stream);
 
+/* Row A13: fp32 frames [frames][3][pix] in [-1, 1] -> uint8 [frames][pix][3], the reference's exact sequence of fp32 roundings:
+ * convert_range (utils/result_processor.py:4-14, diffusion_trainer/streaming_svd.py:353) + IImage/torch2np truncation
+ * (lib/farancia/libimage/iimage.py:35-36).  Bit-exact with the reference. */
+int svd_frames_to_uint8(const float* X, uint8_t* Y, int32_t frames, int32_t pix, svd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

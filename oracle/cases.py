@@ -90,3 +90,22 @@ def tiny_i2v_inputs():
     return dict(sample=torch.randn(B, 4, Fr, h, w, generator=g), t=torch.tensor(481), fps=torch.tensor([8, 8]),
                 image_latents=torch.randn(B, 4, Fr, h, w, generator=g) * 0.7,
                 image_embeddings=torch.randn(B, cd, generator=g), text=torch.randn(B, TINY_I2V["text_tokens"], cd, generator=g))
+
+
+def range_inputs():
+    """Row A13: frames [4, 3, 16, 32] in [-1, 1]: seeded uniform values, plus next to every integer boundary k / 127.5 - 1 the
+    fp32 neighbours (-2 .. +2 ulp) where the reference's truncating uint8 conversion flips."""
+    g = _gen(4242)
+    x = torch.rand(4, 3, 16, 32, generator=g) * 2 - 1
+    k = torch.arange(0, 256, dtype=torch.float64)
+    edge = (k / 127.5 - 1).float()
+    flat = x.view(-1)
+    vals = []
+    for d in (-2, -1, 0, 1, 2):
+        e = edge.clone()
+        for _ in range(abs(d)):
+            e = torch.nextafter(e, torch.full_like(e, 2.0 if d > 0 else -2.0))
+        vals.append(e)
+    vals = torch.cat(vals).clamp(-1, 1)
+    flat[: vals.numel()] = vals
+    return x

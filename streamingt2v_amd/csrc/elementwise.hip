@@ -156,6 +156,27 @@ inline unsigned grid_for(int64_t n, int bs = 256) {
     return (unsigned)g;
 }
 
+// Row A13: the reference's range / quantisation glue, bit for bit.  convert_range([-1,1] -> [0,255]) (utils/result_processor.py:4-14,
+// called at diffusion_trainer/streaming_svd.py:353) then IImage(vmin=0, vmax=255) -> torch2np (lib/farancia/libimage/iimage.py:35-36):
+//   ((v + 1) / 2) * 255  ->  clip(0, 255)  ->  (255 * x) / 255  ->  NHWC  ->  uint8 by TRUNCATION.
+// Every step is a separately rounded fp32 operation in the reference (no FMA contraction): explicit _rn intrinsics.
+__global__ __launch_bounds__(256) void frames_to_uint8_kernel(const float* __restrict__ X, uint8_t* __restrict__ Y, int64_t total, int pix) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t f = i / pix, p = i - f * pix;
+        const float* x = X + f * 3 * pix + p;
+        uint8_t* y = Y + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = x[(int64_t)c * pix];
+            v = __fdiv_rn(__fadd_rn(v, 1.0f), 2.0f);
+            v = __fmul_rn(v, 255.0f);
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+            v = __fdiv_rn(__fmul_rn(255.0f, v), 255.0f);
+            y[c] = (uint8_t)v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int svd_nchw_to_tokens(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
@@ -231,5 +252,15 @@ extern "C" int svd_ae_time_mix3(const float* X, int64_t ldx, const float* w, con
     hipLaunchKernelGGL(ae_time_mix3_kernel, dim3(grid_for((int64_t)frames * pix)), dim3(256), 0, (hipStream_t)stream, X, ldx, w, b,
                        Y, frames, pix, clamp);
     SVD_CHECK_LAUNCH("ae_time_mix3");
+    return SVD_OK;
+}
+
+extern "C" int svd_frames_to_uint8(const float* X, uint8_t* Y, int32_t frames, int32_t pix, svd_stream_t stream) {
+    if (!X || !Y || frames <= 0 || pix <= 0) return SVD_EINVAL;
+    const int64_t total = (int64_t)frames * pix;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(frames_to_uint8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, Y, total, pix);
+    SVD_CHECK_LAUNCH("frames_to_uint8");
     return SVD_OK;
 }

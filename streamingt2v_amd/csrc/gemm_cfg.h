@@ -2,6 +2,10 @@
 #pragma once
 #include "svd_common.h"
 
+#ifndef SVD_GEMM_BK32_WAVES
+#define SVD_GEMM_BK32_WAVES 2   /* waves per SIMD that the 4-wave, 64-accumulator, BK 32 configurations are compiled for */
+#endif
+
 namespace svd_gemm_detail {
 
 
@@ -14,7 +18,7 @@ struct GemmCfg {
     static constexpr int GROUPS = PINGPONG ? 2 : 1;  // ping-pong: two independent wave groups per workgroup, half an iteration apart
     static constexpr int THREADS = NT * GROUPS;
     // register budget: 4-wave workgroups with <= 64 accumulator registers per lane must fit twice per SIMD (2 WG / CU)
-    static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && WM * WN == 4 && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64 || BK_ == 32)) ? 2 : 1;   // BK 32 + 128 accumulators: 2 x 58 KB LDS, 256 registers
+    static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && WM * WN == 4 && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64 || BK_ == 32)) ? ((BK_ == 32 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? SVD_GEMM_BK32_WAVES : 2) : 1;   // BK 32 + 128 accumulators: 2 x 58 KB LDS, 256 registers
     static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     static constexpr int ROWB = BK * 2;       // bytes per LDS row
     static constexpr int SLOTS = BK / 8;      // 16-byte slots per row

@@ -331,3 +331,12 @@ def ddim_cfg_step(x, pred_uncond, pred_cond, guidance_scale, alpha_t, alpha_prev
     check(_lib.svd_ddim_cfg_step(_p(x), _p(pred_uncond), _p(pred_cond), _p(out), x.numel(), float(guidance_scale), float(alpha_t),
                                  float(alpha_prev), int(v_prediction), _stream()), "svd_ddim_cfg_step")
     return out
+
+
+def frames_to_uint8(frames):
+    """fp32 [F, 3, H, W] in [-1, 1] -> uint8 [F, H, W, 3]; bit-exact with the reference's convert_range + IImage (row A13)."""
+    assert frames.dtype == torch.float32 and frames.is_contiguous() and frames.shape[1] == 3
+    F_, _, H, W = frames.shape
+    out = torch.empty((F_, H, W, 3), dtype=torch.uint8, device=frames.device)
+    check(_lib.svd_frames_to_uint8(_p(frames), _p(out), F_, H * W, _stream()), "svd_frames_to_uint8")
+    return out

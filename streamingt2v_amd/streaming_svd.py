@@ -15,6 +15,7 @@ import math
 
 import torch
 
+from . import ops
 from .sampling import EulerEDMSampler
 
 
@@ -93,3 +94,9 @@ class StreamingSVD:
             result = self._generate_conditional_output(c, uc, ctrl_frames, noises[k], num_steps=num_steps)
             result_chunks.append(result[Tc:])                             # the overlap frames are re-generated, dropped
         return torch.cat(result_chunks, dim=0)
+
+    @staticmethod
+    def to_uint8_video(frames):
+        """[-1, 1] fp32 frames [F, 3, H, W] -> uint8 [F, H, W, 3] exactly as the reference stores its result
+        (convert_range at streaming_svd.py:353 + IImage/torch2np truncation, iimage.py:35-36)."""
+        return ops.frames_to_uint8(frames.float().contiguous())

@@ -238,3 +238,18 @@ def test_cfg_pair_split_equals_full_batch(tiny):
         ops.edm_euler_step(x, torch.cat(halves, 0), g, s, s_next)
     # not bit-identical: M halves, so tuned tile shapes and GroupNorm chunking differ -> a different (equally valid) rounding path
     report("CFG-pair split vs CFG batch 2 (2 sampler steps)", x, z_full, rel_tol=3e-2)
+
+
+def test_range_quantisation_bit_exact():
+    """Row A13: [-1,1] frames -> uint8 NHWC, bit for bit the reference's convert_range + IImage/torch2np output (golden bytes
+    produced by the unmodified reference functions, oracle/make_golden_range.py) and the CPU oracle."""
+    from oracle import cases
+    from oracle.range_oracle import frames_to_uint8
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    x = cases.range_inputs()
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "range_tiny.pt"))["u8"]
+    got = StreamingSVD.to_uint8_video(x.cuda()).cpu()
+    assert got.dtype == torch.uint8 and torch.equal(got, gold)
+    g = torch.Generator(); g.manual_seed(7)
+    big = (torch.rand(3, 3, 576, 1024, generator=g) * 2.2 - 1.1).clamp(-1, 1)        # full frame size incl. saturated values
+    assert torch.equal(StreamingSVD.to_uint8_video(big.cuda()).cpu(), frames_to_uint8(big))

@@ -109,3 +109,11 @@ def test_ddim_schedule_properties():
     prev = d.step(v, t, xt)
     a_prev = d.alphas_cumprod[t - 33]
     assert torch.allclose(prev, a_prev.sqrt() * x0 + (1 - a_prev).sqrt() * eps, atol=1e-5)
+
+
+def test_range_oracle_matches_reference_bytes(golden_dir):
+    """Row A13: the range/uint8 restatement reproduces the reference functions' bytes exactly (golden from the real functions)."""
+    from oracle.range_oracle import frames_to_uint8
+    gold = torch.load(os.path.join(golden_dir, "range_tiny.pt"))["u8"]
+    out = frames_to_uint8(cases.range_inputs())
+    assert out.dtype == torch.uint8 and torch.equal(out, gold)
