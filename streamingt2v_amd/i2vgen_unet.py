@@ -307,6 +307,22 @@ class I2VGenXLUNet:
         self.conv_out = _Conv3("conv_out.", c0, cfg.out_channels)
         self._const = None
 
+    # -------------------------------------------------------------------------------------------- reference API shims
+    @property
+    def config(self):
+        """`unet.config.in_channels` / `.cross_attention_dim` as read by the pipeline (pipeline_i2vgen_xl.py:819)."""
+        return self.cfg
+
+    def enable_forward_chunking(self, chunk_size=None, dim=0):
+        """Memory-only knob of the reference (unet_i2vgen_xl.py:440-470); results do not depend on it: no-op here."""
+        return None
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
     # -------------------------------------------------------------------------------------------- parameters
     def _modules(self):
         yield self.conv_in; yield self.transformer_in

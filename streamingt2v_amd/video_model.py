@@ -394,6 +394,17 @@ class UNetConfig:
 class _EncoderBase:
     """Shared encoder half (time/label embedding, input_blocks, middle_block) of VideoUNet and ControlNet."""
 
+    def enable_forward_chunking(self, dim=0, num_chunks=1):
+        """Reference API (video_model.py:498-534, controlnet.py): chunked feed-forward to save memory.  Chunking a row-wise
+        feed-forward does not change its result; with 288 GB of HBM the full tensors stay resident, so this is a no-op."""
+        return None
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def eval(self):
+        return self
+
     def _build_encoder(self, cfg):
         mc, emb = cfg.model_channels, cfg.model_channels * 4
         self.cfg, self.mc, self.emb_ch = cfg, mc, emb
