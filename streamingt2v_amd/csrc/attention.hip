@@ -1,6 +1,5 @@
 // Attention kernels for gfx950 (head dim 64 everywhere in the StreamingSVD UNet / ControlNet / CAM).
 #include "svd_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -366,7 +365,7 @@ extern "C" int svd_attn_cross_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16
     // 8 waves (256 queries) per workgroup for long sequences: every workgroup streams ALL keys/values of its (frame, head) through
     // LDS, so queries per workgroup set the L2 -> LDS traffic per FLOP (4 waves: 128 FLOP/B = 7 TB/s at 900 TFLOP/s, measured to
     // be the limit); 4 waves for short sequences (more workgroups, less tail).
-    const bool wide = n_q >= 2048 && ((uint64_t)(uintptr_t)getenv("SVD_ATTN_NW4") == 0);
+    const bool wide = n_q >= 2048;                     // measured: 906-927 vs 876-896 TFLOP/s at 9216 / 14400 tokens
     const int nw = wide ? 8 : 4;
     const int qblocks = (n_q + nw * 32 - 1) / (nw * 32);
     const int64_t nwg = (int64_t)frames * heads * qblocks;
