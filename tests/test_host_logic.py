@@ -127,3 +127,33 @@ def test_image_to_video_chunk_arithmetic():
     assert calls == ["init"] + ["ar"] * 5 and out.shape[0] == 100
     out = m.image_to_video(lambda a: ({}, {}), torch.zeros(3, 2, 2), 25, [None])
     assert out.shape[0] == 25
+
+
+def test_ddim_schedule_host_tables_match_oracle():
+    """enhance.DDIMSchedule (host tables feeding svd_ddim_cfg_step) vs the oracle's DDIM restatement: timesteps, SDEdit start, alphas."""
+    import torch
+    from oracle.i2vgen_oracle import DDIM
+    from streamingt2v_amd.enhance import DDIMSchedule
+    ours, ora = DDIMSchedule(), DDIM()
+    for n in (30, 10, 50):
+        ora.set_timesteps(n)
+        assert ours.set_timesteps(n) == ora.timesteps.tolist()
+    ora.set_timesteps(30)
+    assert ours.get_timesteps(30, 0.97) == ora.timesteps.tolist()[1:] and len(ours.get_timesteps(30, 0.97)) == 29
+    for t in ours.get_timesteps(30, 0.97):
+        a_t, a_prev = ours.alphas(t)
+        prev = t - 1000 // 30
+        assert abs(a_t - ora.alphas_cumprod[t].item()) < 1e-7
+        assert abs(a_prev - (ora.alphas_cumprod[prev].item() if prev >= 0 else ora.final_alpha_cumprod.item())) < 1e-7
+    g = torch.Generator(); g.manual_seed(0)
+    x, n = torch.randn(1, 4, 3, 5, 5, generator=g), torch.randn(1, 4, 3, 5, 5, generator=g)
+    assert torch.allclose(ours.add_noise(x, n, 958), ora.add_noise(x, n, 958), atol=1e-6)
+
+
+def test_i2v_spec_parameter_count():
+    """The enhancer mirror declares the reference architecture: 1511 tensors / 1420.5 M parameters at full size."""
+    import math
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    spec = I2VGenXLUNet(I2VConfig()).spec()
+    assert len(spec) == 1511
+    assert abs(sum(math.prod(s) for _, s in spec) / 1e6 - 1420.5) < 0.1
