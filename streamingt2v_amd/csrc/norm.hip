@@ -6,9 +6,11 @@ namespace {
 constexpr int GN_MAXCHUNK = 256;
 
 __host__ __device__ inline int gn_nchunk(int frames, int pix) {
-    int n = (2048 + frames - 1) / frames;
-    const int maxc = (pix + 31) / 32;
-    if (n > maxc) n = maxc;
+    // chunks of ~256 rows, a function of the frame size ONLY: the partial-sum grouping (and so every rounding of the statistics)
+    // is then independent of how many frames are batched -- forward(batch 2) == concat(forward(half), forward(half)) bit for
+    // bit, which is what makes the CFG-pair split over two GPUs exact (tests/test_gpu_fullsize.py)
+    (void)frames;
+    int n = (pix > 4096) ? (pix + 255) / 256 : (pix + 63) / 64;      // small frames: smaller chunks keep > 256 workgroups in flight
     if (n > GN_MAXCHUNK) n = GN_MAXCHUNK;
     if (n < 1) n = 1;
     return n;
@@ -19,7 +21,7 @@ __host__ __device__ inline int gn_nchunk(int frames, int pix) {
 template <class E>
 __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t ldx, int pix, int channels, int groups,
                                         int nchunk, float* __restrict__ partial) {
-    extern __shared__ float sch[];   // [channels][2]
+    extern __shared__ float sch[];   // [R][channels][2]: one slot per (row group, channel) -- summed in a FIXED order below
     const int octets = channels >> 3;
     const int R = blockDim.x / octets;
     const int o = threadIdx.x % octets, rr = threadIdx.x / octets;
@@ -27,8 +29,6 @@ __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t 
     const int rows_per_chunk = (pix + nchunk - 1) / nchunk;
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk; if (r1 > pix) r1 = pix;
-    for (int i = threadIdx.x; i < 2 * channels; i += blockDim.x) sch[i] = 0.f;
-    __syncthreads();
     float s[8], ss[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
@@ -48,17 +48,20 @@ __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t 
             acc8(u0); acc8(u1); acc8(u2); acc8(u3);
         }
         for (; r < r1; r += R) acc8(*(const uint4*)(base + (int64_t)r * ldx));
+        float* dst = sch + ((int64_t)rr * channels + o * 8) * 2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            atomicAdd(&sch[(o * 8 + i) * 2 + 0], s[i]);
-            atomicAdd(&sch[(o * 8 + i) * 2 + 1], ss[i]);
-        }
+        for (int i = 0; i < 8; ++i) { dst[2 * i] = s[i]; dst[2 * i + 1] = ss[i]; }
     }
     __syncthreads();
+    // deterministic: group g = fixed-order sum over its channels and over the R row groups (no atomics anywhere in the path:
+    // bit-identical results from run to run, tests/test_gpu_fullsize.py)
     const int cpg = channels / groups;
     if ((int)threadIdx.x < groups) {
         float a = 0.f, b = 0.f;
-        for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { a += sch[2 * c]; b += sch[2 * c + 1]; }
+        for (int q = 0; q < R; ++q)
+            for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
+                a += sch[((int64_t)q * channels + c) * 2]; b += sch[((int64_t)q * channels + c) * 2 + 1];
+            }
         float* p = partial + (((int64_t)f * nchunk + chunk) * groups + threadIdx.x) * 2;
         p[0] = a; p[1] = b;
     }
@@ -247,7 +250,7 @@ extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frame
     if ((uintptr_t)X & 15) return SVD_EINVAL;
     const int nchunk = gn_nchunk(frames, pix);
     const int bs = gn_block(channels);
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_stats_partial_kernel<E>, dim3(nchunk, frames), dim3(bs), 2 * channels * sizeof(float),
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_stats_partial_kernel<E>, dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
                                                  (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
     SVD_CHECK_LAUNCH("gn_stats_partial");
     const int nstat = frames / frames_per_stat;

@@ -1,0 +1,95 @@
+"""Full-size (BASELINE configs[1]: 2 x 25 frames @ latent 72x128, full 1.59 B-parameter VideoUNet) checks through size-independent
+properties -- the CPU oracle needs ~7 minutes per forward at this size, so parity here is structural:
+
+  * determinism: the path has no atomics; two runs are bit-identical;
+  * CFG-batch independence: nothing in the forward couples the two CFG halves (per-sample GroupNorm statistics, per-frame and
+    per-pixel attention) => forward(batch 2) == concat(forward(uncond half), forward(cond half)) bit for bit -- this is also what
+    makes the CFG-pair split over two GPUs exact;
+  * GEMM tile-configuration independence: every configuration accumulates K in the same order => identical bits at M = 460 800;
+  * attention: softmax rows sum to 1 (V = 1 => O = 1) and the result does not depend on the order of the keys (up to
+    reassociation noise) at N = 9216.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_unet():
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.video_model import UNetConfig, VideoUNet
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    ops.set_element_dtype(torch.bfloat16)
+    unet = VideoUNet(UNetConfig())
+    unet.load_state_dict(init_by_name(unet.spec(), seed=33, device="cuda"), device="cuda")
+    torch.cuda.empty_cache()
+    return StreamingWrapper(unet, None, 7)
+
+
+def _inputs(T=25, h=72, w=128):
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    x, t = r(2 * T, 4, h, w), r(2 * T) * 0.5
+    c = dict(concat=r(2 * T, 4, h, w) * 0.5, crossattn=r(2, 1, 1024).repeat_interleave(T, 0), vector=r(2, 768).repeat_interleave(T, 0) * 0.5)
+    return x, t, c
+
+
+def test_full_size_forward_deterministic_and_cfg_halves_independent(full_unet):
+    T = 25
+    x, t, c = _inputs(T)
+    kw = dict(num_video_frames=T, ctrl_frames=None)
+    with torch.no_grad():
+        a = full_unet.forward(x, t, c, batch_size=2, image_only_indicator=torch.zeros(2, T, device="cuda"), **kw)
+        b = full_unet.forward(x, t, c, batch_size=2, image_only_indicator=torch.zeros(2, T, device="cuda"), **kw)
+        halves = [full_unet.forward(x[s], t[s], {k: v[s] for k, v in c.items()}, batch_size=1,
+                                    image_only_indicator=torch.zeros(1, T, device="cuda"), **kw)
+                  for s in (slice(0, T), slice(T, 2 * T))]
+    assert a.shape == (2 * T, 4, 72, 128) and torch.isfinite(a).all() and a.float().std() > 1e-3
+    assert torch.equal(a, b), "forward is not deterministic"
+    assert torch.equal(a, torch.cat(halves, 0)), "the CFG halves are not independent"
+
+
+def test_full_size_gemm_tile_config_independence():
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.video_model import pack_geglu
+    ops.set_element_dtype(torch.bfloat16)
+    M, K, N = 460800, 320, 2560
+    g = torch.Generator(device="cuda"); g.manual_seed(6)
+    a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5)
+    b = torch.randn(N, generator=g, device="cuda")
+    wp, bp = pack_geglu(w, b)
+    wp = wp.to(torch.bfloat16)
+    ref = ops.gemm(a, wp, bias=bp, geglu=True, tile_cfg=1)
+    for cfg in (2, 8, 9, 17, 18, 19, 20):
+        assert torch.equal(ops.gemm(a, wp, bias=bp, geglu=True, tile_cfg=cfg), ref), f"tile config {cfg} changes the bits"
+    r = torch.randn(M, 320, generator=g, device="cuda").to(torch.bfloat16)
+    w2 = (torch.randn(320, 1280, generator=g, device="cuda") * 1280 ** -0.5).to(torch.bfloat16)
+    ref = ops.gemm(ref, w2, bias=b[:320].contiguous(), residual=r, tile_cfg=1)
+    x = ops.gemm(a, wp, bias=bp, geglu=True, tile_cfg=8)
+    for cfg in (2, 4, 8, 13, 17, 20):
+        assert torch.equal(ops.gemm(x, w2, bias=b[:320].contiguous(), residual=r, tile_cfg=cfg), ref), f"tile config {cfg} changes the bits"
+
+
+def test_full_size_attention_properties():
+    from streamingt2v_amd import ops
+    ops.set_element_dtype(torch.bfloat16)
+    frames, n, heads = 4, 9216, 5
+    C = heads * 64
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    q = torch.randn(frames * n, C, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(frames * n, C, generator=g, device="cuda").to(torch.bfloat16)
+    ones_t = torch.ones(frames, C, n, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty_like(q)
+    ops.attn_spatial(q, k, ones_t, out, frames, n, heads)
+    assert (out.float() - 1).abs().max().item() <= 2 ** -7, "softmax rows do not sum to 1"
+    v = torch.randn(frames, n, C, generator=g, device="cuda").to(torch.bfloat16)
+    o1, o2 = torch.empty_like(q), torch.empty_like(q)
+    ops.attn_spatial(q, k, v.transpose(1, 2).contiguous(), o1, frames, n, heads)
+    perm = torch.randperm(n, generator=g, device="cuda")
+    kp = k.view(frames, n, C)[:, perm].reshape(frames * n, C).contiguous()
+    vp = v[:, perm].transpose(1, 2).contiguous()
+    ops.attn_spatial(q, kp, vp, o2, frames, n, heads)
+    assert (o1.float() - o2.float()).abs().max().item() <= 2e-3, "attention depends on the key order"
