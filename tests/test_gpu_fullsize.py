@@ -118,3 +118,26 @@ def test_full_size_enhancer_deterministic_and_cfg_halves_independent():
     assert a.shape == (2, 4, Fr, H, W) and torch.isfinite(a).all() and a.float().std() > 1e-3
     assert torch.equal(a, b), "enhancer forward is not deterministic"
     assert torch.equal(a, torch.cat(halves, 0)), "the enhancer's CFG halves are not independent"
+
+
+def test_full_size_vae_decode_deterministic():
+    """Temporal-VAE decode of one 8-frame group at 576x1024 (1.2 GB activations at the top level): bit-identical reruns, finite,
+    and sensitive to its input (every frame depends on every latent frame of the group: the time-stack GroupNorms pool their
+    statistics over the group's frames)."""
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VideoDecoder
+    ops.set_element_dtype(torch.bfloat16)
+    dec = VideoDecoder()
+    dec.load_state_dict(init_by_name(dec.spec(), seed=35, device="cuda"), device="cuda")
+    vae = AutoencodingEngineDecoder(dec)
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    z = torch.randn(8, 4, 72, 128, generator=g, device="cuda")
+    with torch.no_grad():
+        a = vae.decode(z, timesteps=8).clone()
+        b = vae.decode(z, timesteps=8).clone()
+        z2 = z.clone(); z2[7] += 1.0
+        c = vae.decode(z2, timesteps=8).clone()
+    assert a.shape == (8, 3, 576, 1024) and torch.isfinite(a).all()
+    assert torch.equal(a, b), "decode is not deterministic"
+    assert not torch.equal(a[7], c[7]) and not torch.equal(a[0], c[0])
