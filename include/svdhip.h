@@ -125,7 +125,7 @@ int svd_attn_cross_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16* K, int64_
                        int32_t frames, int32_t n_q, int32_t n_k, int32_t frames_per_kv, int32_t heads,
                        int32_t dtype, svd_stream_t stream);
 
-/* Per-pixel temporal attention over short sequences (<= 64; <= 32 uses half-waves), head dim 64.
+/* Per-pixel temporal attention over short sequences (<= 128 frames: 32 -> half-waves, 64 -> waves, 128 -> waves with two query passes), head dim 64.
  * Also the two self-attentions of the enhancer's TransformerTemporalModel (code/i2v_enhance/transformer_temporal.py:160-195,
  * 38-frame chunks).
  * Replaces the attention inside VideoTransformerBlock.attn1 (models/svd/sgm/modules/video_attention.py:145-148,

@@ -194,23 +194,25 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
 // happen.  One half-wave (32 lanes) per (batch, pixel, head): lane i holds query i in fp32 registers; K and V of
 // the problem sit in LDS (bf16) and are read as wave-broadcast 16-byte vectors.
 // ------------------------------------------------------------------------------------------------------------
-// TA_MAXT = 32: one half-wave per problem (8 per workgroup); TA_MAXT = 64 (the I2VGen-XL enhancer's 38-frame chunks): one wave.
-template <class E, int TA_MAXT>
-__global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
+// Three instantiations: <32 keys, 32 lanes, 8 problems per workgroup> (SVD: 25 frames, CAM 25 x 7), <64, 64, 4> (the enhancer's
+// 38-frame windows) and <128, 64, 2> (the enhancer without blending: ONE window of up to 128 frames, the reference's default
+// when --use_randomized_blending is not given).  LANES lanes serve one problem; queries beyond LANES are handled in passes that
+// share the staged K/V.
+template <class E, int TA_MAXT, int LANES, int NG>
+__global__ __launch_bounds__(LANES * NG) void attn_temporal_d64_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ V, int64_t ldv, svd_bf16* __restrict__ O, int64_t ldo,
     int batch, int tq, int tk, int n_pix, int heads, int64_t n_prob) {
-    constexpr int NG = 256 / TA_MAXT;   // problems per workgroup
     __shared__ __attribute__((aligned(16))) uint16_t sKV[NG][2][TA_MAXT][64];   // 64 KiB
     const int tid = threadIdx.x;
-    const int hw = tid / TA_MAXT;       // lane group (half-wave or wave) = problem slot
-    const int li = tid % TA_MAXT;
+    const int hw = tid / LANES;         // lane group = problem slot
+    const int li = tid % LANES;
     const float c = 0.125f;
 
     for (int64_t base = (int64_t)blockIdx.x * NG; base < n_prob; base += (int64_t)gridDim.x * NG) {
         const int64_t prob = base + hw;
         const bool active = prob < n_prob;
-        // problem index -> (b, p, h) with h fastest: the 8 half-waves of a block read adjacent channels/pixels
+        // problem index -> (b, p, h) with h fastest: the lane groups of a block read adjacent channels/pixels
         int b = 0, pp = 0, h = 0;
         if (active) {
             h = (int)(prob % heads);
@@ -219,81 +221,83 @@ __global__ __launch_bounds__(256) void attn_temporal_d64_kernel(
         }
         __syncthreads();   // previous iteration's LDS reads done
         if (active) {
-            // stage K,V: tk rows x 128 B each = tk*8 16-byte vectors per matrix, spread over the 32 lanes
-            for (int v = li; v < tk * 8; v += TA_MAXT) {
+            // stage K,V: tk rows x 128 B each = tk*8 16-byte vectors per matrix, spread over the group's lanes
+            for (int v = li; v < tk * 8; v += LANES) {
                 const int j = v >> 3, sl = v & 7;
                 const int64_t row = ((int64_t)b * tk + j) * n_pix + pp;
                 *(uint4*)&sKV[hw][0][j][sl * 8] = *(const uint4*)(K + row * ldk + h * 64 + sl * 8);
                 *(uint4*)&sKV[hw][1][j][sl * 8] = *(const uint4*)(V + row * ldv + h * 64 + sl * 8);
             }
         }
-        float q[64];
-        const bool qact = active && li < tq;
-        {
-            const int qi = li < tq ? li : tq - 1;
-            const int64_t row = ((int64_t)b * tq + qi) * n_pix + pp;
-            const svd_bf16* qp = Q + row * ldq + h * 64;
-#pragma unroll
-            for (int d = 0; d < 64; d += 8) {
-                uint4 u = active ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
-                q[d + 0] = E::lo(u.x); q[d + 1] = E::hi(u.x);
-                q[d + 2] = E::lo(u.y); q[d + 3] = E::hi(u.y);
-                q[d + 4] = E::lo(u.z); q[d + 5] = E::hi(u.z);
-                q[d + 6] = E::lo(u.w); q[d + 7] = E::hi(u.w);
-            }
-        }
         __syncthreads();
-        // scores
-        float s[TA_MAXT];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < TA_MAXT; ++j) {
-            if (j < tk) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-                for (int d = 0; d < 64; d += 8) {
-                    const uint4 u = *(const uint4*)&sKV[hw][0][j][d];
-                    a0 += q[d + 0] * E::lo(u.x); a1 += q[d + 1] * E::hi(u.x);
-                    a2 += q[d + 2] * E::lo(u.y); a3 += q[d + 3] * E::hi(u.y);
-                    a0 += q[d + 4] * E::lo(u.z); a1 += q[d + 5] * E::hi(u.z);
-                    a2 += q[d + 6] * E::lo(u.w); a3 += q[d + 7] * E::hi(u.w);
-                }
-                s[j] = ((a0 + a1) + (a2 + a3)) * c;
-                mx = fmaxf(mx, s[j]);
-            } else s[j] = -INFINITY;
-        }
-        float l = 0.f;
-#pragma unroll
-        for (int j = 0; j < TA_MAXT; ++j) {
-            if (j < tk) { s[j] = __expf(s[j] - mx); l += s[j]; }
-        }
-        const float inv = 1.f / l;
-        // output (reuse q registers as accumulators)
-#pragma unroll
-        for (int d = 0; d < 64; ++d) q[d] = 0.f;
-#pragma unroll
-        for (int j = 0; j < TA_MAXT; ++j) {
-            if (j < tk) {
-                const float pj = s[j] * inv;
+        for (int q0 = 0; q0 < tq; q0 += LANES) {       // query passes (one unless tq > LANES)
+            float q[64];
+            const bool qact = active && q0 + li < tq;
+            {
+                const int qi = q0 + li < tq ? q0 + li : tq - 1;
+                const int64_t row = ((int64_t)b * tq + qi) * n_pix + pp;
+                const svd_bf16* qp = Q + row * ldq + h * 64;
 #pragma unroll
                 for (int d = 0; d < 64; d += 8) {
-                    const uint4 u = *(const uint4*)&sKV[hw][1][j][d];
-                    q[d + 0] += pj * E::lo(u.x); q[d + 1] += pj * E::hi(u.x);
-                    q[d + 2] += pj * E::lo(u.y); q[d + 3] += pj * E::hi(u.y);
-                    q[d + 4] += pj * E::lo(u.z); q[d + 5] += pj * E::hi(u.z);
-                    q[d + 6] += pj * E::lo(u.w); q[d + 7] += pj * E::hi(u.w);
+                    uint4 u = active ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+                    q[d + 0] = E::lo(u.x); q[d + 1] = E::hi(u.x);
+                    q[d + 2] = E::lo(u.y); q[d + 3] = E::hi(u.y);
+                    q[d + 4] = E::lo(u.z); q[d + 5] = E::hi(u.z);
+                    q[d + 6] = E::lo(u.w); q[d + 7] = E::hi(u.w);
                 }
             }
-        }
-        if (qact) {
-            const int64_t row = ((int64_t)b * tq + li) * n_pix + pp;
-            svd_bf16* op = O + row * ldo + h * 64;
+            // scores
+            float s[TA_MAXT];
+            float mx = -INFINITY;
 #pragma unroll
-            for (int d = 0; d < 64; d += 8) {
-                uint4 u;
-                u.x = E::pack(q[d + 0], q[d + 1]); u.y = E::pack(q[d + 2], q[d + 3]);
-                u.z = E::pack(q[d + 4], q[d + 5]); u.w = E::pack(q[d + 6], q[d + 7]);
-                *(uint4*)(op + d) = u;
+            for (int j = 0; j < TA_MAXT; ++j) {
+                if (j < tk) {
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 64; d += 8) {
+                        const uint4 u = *(const uint4*)&sKV[hw][0][j][d];
+                        a0 += q[d + 0] * E::lo(u.x); a1 += q[d + 1] * E::hi(u.x);
+                        a2 += q[d + 2] * E::lo(u.y); a3 += q[d + 3] * E::hi(u.y);
+                        a0 += q[d + 4] * E::lo(u.z); a1 += q[d + 5] * E::hi(u.z);
+                        a2 += q[d + 6] * E::lo(u.w); a3 += q[d + 7] * E::hi(u.w);
+                    }
+                    s[j] = ((a0 + a1) + (a2 + a3)) * c;
+                    mx = fmaxf(mx, s[j]);
+                } else s[j] = -INFINITY;
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < TA_MAXT; ++j) {
+                if (j < tk) { s[j] = __expf(s[j] - mx); l += s[j]; }
+            }
+            const float inv = 1.f / l;
+            // output (reuse q registers as accumulators)
+#pragma unroll
+            for (int d = 0; d < 64; ++d) q[d] = 0.f;
+#pragma unroll
+            for (int j = 0; j < TA_MAXT; ++j) {
+                if (j < tk) {
+                    const float pj = s[j] * inv;
+#pragma unroll
+                    for (int d = 0; d < 64; d += 8) {
+                        const uint4 u = *(const uint4*)&sKV[hw][1][j][d];
+                        q[d + 0] += pj * E::lo(u.x); q[d + 1] += pj * E::hi(u.x);
+                        q[d + 2] += pj * E::lo(u.y); q[d + 3] += pj * E::hi(u.y);
+                        q[d + 4] += pj * E::lo(u.z); q[d + 5] += pj * E::hi(u.z);
+                        q[d + 6] += pj * E::lo(u.w); q[d + 7] += pj * E::hi(u.w);
+                    }
+                }
+            }
+            if (qact) {
+                const int64_t row = ((int64_t)b * tq + q0 + li) * n_pix + pp;
+                svd_bf16* op = O + row * ldo + h * 64;
+#pragma unroll
+                for (int d = 0; d < 64; d += 8) {
+                    uint4 u;
+                    u.x = E::pack(q[d + 0], q[d + 1]); u.y = E::pack(q[d + 2], q[d + 3]);
+                    u.z = E::pack(q[d + 4], q[d + 5]); u.w = E::pack(q[d + 6], q[d + 7]);
+                    *(uint4*)(op + d) = u;
+                }
             }
         }
     }
@@ -393,19 +397,20 @@ extern "C" int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_b
                                      int32_t batch, int32_t tq, int32_t tk, int32_t n_pix, int32_t heads,
                                      int32_t dtype, svd_stream_t stream) {
     if (!Q || !K || !V || !O || batch <= 0 || n_pix <= 0 || heads <= 0) return SVD_EINVAL;
-    if (tq <= 0 || tk <= 0 || tq > 64 || tk > 64) return SVD_EINVAL;
+    if (tq <= 0 || tk <= 0 || tq > 128 || tk > 128) return SVD_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return SVD_EINVAL;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return SVD_EINVAL;
     const int64_t n_prob = (int64_t)batch * n_pix * heads;
-    const bool small = tq <= 32 && tk <= 32;
-    int64_t blocks = small ? (n_prob + 7) / 8 : (n_prob + 3) / 4;
+    const int ng = (tq <= 32 && tk <= 32) ? 8 : (tk <= 64 ? 4 : 2);
+    int64_t blocks = (n_prob + ng - 1) / ng;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (small)
-        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_d64_kernel<E, 32>), dim3((unsigned)blocks), dim3(256), 0,
-                                                     (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
-    else
-        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_d64_kernel<E, 64>), dim3((unsigned)blocks), dim3(256), 0,
-                                                     (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
+#define SVD_TA_LAUNCH(MAXT, LANES, NG)                                                                                           \
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_d64_kernel<E, MAXT, LANES, NG>), dim3((unsigned)blocks), dim3(LANES * NG), 0, \
+                                                 (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob))
+    if (ng == 8) SVD_TA_LAUNCH(32, 32, 8);
+    else if (ng == 4) SVD_TA_LAUNCH(64, 64, 4);
+    else SVD_TA_LAUNCH(128, 64, 2);
+#undef SVD_TA_LAUNCH
     SVD_CHECK_LAUNCH("attn_temporal_d64");
     return SVD_OK;
 }

@@ -1,0 +1,147 @@
+"""`inference_i2v.py`-compatible front end: the call surface of the reference's ``StreamingPipeline``
+(code/inference_i2v.py:52-258) on the MI355X path, without Lightning / jsonargparse.
+
+    pipe = StreamingPipeline.from_checkpoint("model.safetensors", conditioner=...)       # init_model, :125-160
+    video = pipe.image_to_video(image, num_frames=100)                                    # :179-190  -> uint8 [F, H, W, 3]
+    video = pipe.enhance_video(image=image, video=video, use_randomized_blending=True)    # :192-207
+    video = pipe.interpolate_video(video, dest_num_frames=200)                            # :209-223
+
+What is native here: the checkpoint key map (same `state_dict` keys, strict), chunk arithmetic, the AR generation, the
+enhancement loop with randomized blending and its key-frame pre-pass, range conversions.  What is an injected callable
+(not on the measured path): the conditioners -- OpenCLIP image tower + VAE encoder for stage 1
+(``conditioner(frame[3,H,W] in [-1,1]) -> (c, uc)``), CLIP text/vision + AutoencoderKL encode/decode for the enhancer
+(``enhance_codec``), and EMA-VFI (``vfi``).  Calling a stage whose callable was not supplied raises NotImplementedError that names it.
+"""
+import math
+import random
+
+import torch
+
+# config.yaml values the reference's front end reads (inference_i2v.py:31-47, config.yaml:2,146-156, i2v_enhance_interface.py:82-131)
+DEFAULTS = dict(num_frames=200, out_fps=24, chunk_size=38, overlap_size=12, use_randomized_blending=False, seed=33,
+                num_frames_per_chunk=25, num_conditional_frames=7, num_steps=30, enhance_steps=30, enhance_strength=0.97,
+                enhance_guidance_scale=9.0, enhance_generator_seed=8888, enhance_height=720, enhance_width=1280,
+                prompt="High Quality, HQ, detailed.",
+                negative_prompt="Distorted, blurry, discontinuous, Ugly, blurry, low resolution, motionless, static, disfigured, "
+                                "disconnected limbs, Ugly faces, incomplete arms")
+
+CKPT_PREFIXES = dict(unet="model.diffusion_model.", controlnet="controlnet.", decoder="first_stage_model.decoder.")
+
+
+def load_streamingsvd_checkpoint(path_or_state_dict, device="cuda", unet_cfg=None, vae_cfg=None):
+    """PAIR/StreamingSVD ``model.safetensors`` (or a Lightning ``.ckpt``) -> (VideoUNet, ControlNet, VideoDecoder) on `device`.
+    Strict: every key under the three prefixes must match our specs (= the reference modules' state_dicts); keys of the parts that
+    stay on the reference side (``conditioner.*``, ``first_stage_model.encoder.*``, ``image_encoder_apm*``) are ignored here."""
+    from .temporal_ae import VaeConfig, VideoDecoder
+    from .video_model import ControlNet, UNetConfig, VideoUNet
+    sd = path_or_state_dict
+    if isinstance(sd, str):
+        if sd.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(sd)
+        else:
+            sd = torch.load(sd, map_location="cpu")["state_dict"]
+    cfg = unet_cfg or UNetConfig()
+    unet = VideoUNet(cfg).load_state_dict(sd, device=device, prefix=CKPT_PREFIXES["unet"])
+    cnet = ControlNet(cfg).load_state_dict(sd, device=device, prefix=CKPT_PREFIXES["controlnet"])
+    dec = VideoDecoder(vae_cfg or VaeConfig()).load_state_dict(sd, device=device, prefix=CKPT_PREFIXES["decoder"])
+    return unet, cnet, dec
+
+
+def num_autoregressive_generations(num_frames, frames_per_chunk=25, num_conditional_frames=7):
+    """inference_i2v.py:182-186."""
+    return max(0, math.ceil((num_frames - frames_per_chunk) / (frames_per_chunk - num_conditional_frames)))
+
+
+def enhance_windows(n_frames, chunk_size, overlap_size):
+    """Window starts of the randomized-blending pass and the number of frames that survive (i2v_enhance_interface.py:88-113):
+    full windows only, stride chunk - overlap; the tail that does not fill a window is dropped."""
+    starts = [i for i in range(0, n_frames, chunk_size - overlap_size) if i + chunk_size <= n_frames]
+    max_idx = (chunk_size - overlap_size) * (len(starts) - 1) + chunk_size if starts else 0
+    return starts, max_idx
+
+
+class StreamingPipeline:
+    def __init__(self, unet, controlnet, decoder, conditioner=None, enhancer_unet=None, enhance_codec=None, vfi=None, **overrides):
+        from .sampling import AlignYourSteps, EulerEDMSampler
+        from .streaming_svd import StreamingSVD
+        from .temporal_ae import AutoencodingEngineDecoder
+        from .wrappers import StreamingWrapper
+        self.cfg = dict(DEFAULTS, **overrides)
+        c = self.cfg
+        sampler = EulerEDMSampler(num_steps=c["num_steps"], num_frames=c["num_frames_per_chunk"], min_scale=1.5, max_scale=3.0,
+                                  discretization=AlignYourSteps())
+        self.model = StreamingSVD(StreamingWrapper(unet, controlnet, c["num_conditional_frames"]), AutoencodingEngineDecoder(decoder),
+                                  sampler, num_conditional_frames=c["num_conditional_frames"])
+        self.conditioner, self.enhancer_unet, self.enhance_codec, self.vfi = conditioner, enhancer_unet, enhance_codec, vfi
+        self.num_frames, self.out_fps = c["num_frames"], c["out_fps"]
+        self.use_randomized_blending, self.chunk_size, self.overlap_size = c["use_randomized_blending"], c["chunk_size"], c["overlap_size"]
+        self.device = unet.device
+
+    @classmethod
+    def from_checkpoint(cls, path, device="cuda", **kw):
+        return cls(*load_streamingsvd_checkpoint(path, device=device), **kw)
+
+    # ------------------------------------------------------------------------------------------ stage 1
+    def image_to_video(self, image, num_frames, seed=None, **kwargs):
+        """image: uint8 [H, W, 3] (numpy or tensor) at 576x1024 (the reference's datamodule resizes before this point) or fp32
+        [3, H, W] in [-1, 1].  Returns uint8 [num_frames, H, W, 3] like trainer.generated_video[:num_frames]."""
+        if self.conditioner is None:
+            raise NotImplementedError("image_to_video needs conditioner(frame) -> (c, uc): the OpenCLIP image tower + VAE encoder of "
+                                      "the reference's GeneralConditioner are not part of the MI355X path (SURVEY.md 8f N4)")
+        img = torch.as_tensor(image)
+        if img.dtype == torch.uint8:
+            img = img.to(self.device).permute(2, 0, 1).float() / 127.5 - 1.0
+        img = img.to(self.device, torch.float32)
+        c = self.cfg
+        T, h, w = c["num_frames_per_chunk"], img.shape[1] // 8, img.shape[2] // 8
+        n_ar = num_autoregressive_generations(num_frames, T, c["num_conditional_frames"])
+        g = torch.Generator(device=self.device)
+        g.manual_seed(c["seed"] if seed is None else seed)                       # seed_everything: 33 (config.yaml:2)
+        noises = [torch.randn(T, 4, h, w, generator=g, device=self.device) for _ in range(1 + n_ar)]
+        video = self.model.image_to_video(self.conditioner, img, num_frames, noises)
+        return self.model.to_uint8_video(video).cpu().numpy()
+
+    # ------------------------------------------------------------------------------------------ enhancement
+    def enhance_video(self, image, video, chunk_size=38, overlap_size=12, strength=0.97, use_randomized_blending=False, **kwargs):
+        """Mirror of enhance_video + i2v_enhance_process (inference_i2v.py:192-207, i2v_enhance_interface.py:82-133).
+        enhance_codec must provide: encode_video(frames uint8 [F,H,W,3] resized to 720x1280) -> latents fp32 [1,4,F,90,160];
+        window_conditioning(image uint8, first_frames, n_windows, window_len) -> list of dicts(fps, image_latents, image_embeddings,
+        text), one per window, unconditional half first; decode(latents) -> uint8 frames; and a torch.Generator for the SDEdit noise."""
+        if self.enhancer_unet is None or self.enhance_codec is None:
+            raise NotImplementedError("enhance_video needs enhancer_unet (I2VGenXLUNet) and enhance_codec (CLIP text/vision towers + "
+                                      "AutoencoderKL encode/decode of the I2VGen-XL pipeline; SURVEY.md 8f N4)")
+        from .enhance import I2VEnhancer
+        c, codec = self.cfg, self.enhance_codec
+        enh = I2VEnhancer(self.enhancer_unet, guidance_scale=c["enhance_guidance_scale"], num_inference_steps=c["enhance_steps"],
+                          strength=strength)
+        rng = random.Random(c["seed"])
+        video = list(video)
+        images = [image]
+        if use_randomized_blending:
+            starts, max_idx = enhance_windows(len(video), chunk_size, overlap_size)
+            key_frames = [video[s] for s in starts]                              # 1st frame of every window, enhanced first
+            lat = codec.encode_video(key_frames)
+            conds = codec.window_conditioning(images, [key_frames[0]], 1, len(key_frames))
+            images = codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng))
+            video = video[:max_idx]
+        else:
+            starts, chunk_size, overlap_size = [0], len(video), 0
+        lat = codec.encode_video(video)
+        conds = codec.window_conditioning(images, [video[s] for s in starts], len(starts), chunk_size)
+        out = enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng)
+        return codec.decode(out)
+
+    def interpolate_video(self, video, dest_num_frames, **kwargs):
+        if self.vfi is None:
+            raise NotImplementedError("interpolate_video needs vfi(video, dest_num_frames): EMA-VFI (code/i2v_enhance/thirdparty/VFI) "
+                                      "is outside the MI355X path (SURVEY.md 8f N4)")
+        return self.vfi(video, dest_num_frames)
+
+    def __call__(self, image):
+        """The script body of inference_i2v.py:226-258 for one image."""
+        n, rb = self.num_frames, self.use_randomized_blending
+        chunk, overlap = (self.chunk_size, self.overlap_size) if rb else ((n + 1) // 2, 0)
+        video = self.image_to_video(image, (n + 1) // 2)
+        video = self.enhance_video(image=image, video=video, use_randomized_blending=rb, chunk_size=chunk, overlap_size=overlap)
+        return self.interpolate_video(video, dest_num_frames=n)

@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu():
     a = GemmArgs()
     assert lib.svd_gemm(ctypes.byref(a), None) == -1
     assert lib.svd_attn_spatial_d64(None, 0, None, 0, None, 0, None, 0, 1, 1, 1, 0, None) == -1
-    assert lib.svd_attn_temporal_d64(None, 0, None, 0, None, 0, None, 0, 1, 64, 1, 1, 1, 0, None) == -1
+    assert lib.svd_attn_temporal_d64(None, 0, None, 0, None, 0, None, 0, 1, 129, 1, 1, 1, 0, None) == -1
     bm, bn, th, lds = (ctypes.c_int() for _ in range(4))
     assert lib.svd_gemm_config_info(1, bm, bn, th, lds) == 0 and (bm.value, bn.value) == (128, 128)
     assert lib.svd_gemm_config_info(99, bm, bn, th, lds) == -1

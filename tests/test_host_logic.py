@@ -157,3 +157,51 @@ def test_i2v_spec_parameter_count():
     spec = I2VGenXLUNet(I2VConfig()).spec()
     assert len(spec) == 1511
     assert abs(sum(math.prod(s) for _, s in spec) / 1e6 - 1420.5) < 0.1
+
+
+def test_pipeline_front_end_chunk_arithmetic_and_windows():
+    """streamingt2v_amd.pipeline vs the reference's expressions (inference_i2v.py:182-186, i2v_enhance_interface.py:88-113)."""
+    import math
+    from streamingt2v_amd import pipeline as P
+    for n in (25, 26, 43, 100, 101, 200):
+        assert P.num_autoregressive_generations(n) == max(0, math.ceil((n - 25) / (25 - 7)))
+    for n, chunk, overlap in ((100, 38, 12), (100, 50, 0), (38, 38, 12), (37, 38, 12), (115, 38, 12), (200, 38, 12)):
+        video = list(range(n))
+        ref_chunks = [video[i:i + chunk] for i in range(0, len(video), chunk - overlap) if len(video[i:i + chunk]) == chunk]
+        starts, max_idx = P.enhance_windows(n, chunk, overlap)
+        assert starts == [c[0] for c in ref_chunks]
+        assert max_idx == ((chunk - overlap) * (len(ref_chunks) - 1) + chunk if ref_chunks else 0)
+    assert P.DEFAULTS["chunk_size"] == 38 and P.DEFAULTS["overlap_size"] == 12 and P.DEFAULTS["num_frames"] == 200
+
+
+def test_pipeline_checkpoint_key_map(tmp_path):
+    """A safetensors checkpoint with the reference's key prefixes loads strictly into the three mirrors; a missing key fails."""
+    import pytest
+    import torch
+    from safetensors.torch import save_file
+    from oracle import cases
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import VaeConfig, VideoDecoder
+    from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    tu, tv = cases.TINY_UNET, cases.TINY_VAE
+    ucfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"],
+                      channel_mult=tu["channel_mult"], conditioning_embedding_out_channels=tu["cond_embed"])
+    vcfg = VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])
+    sd = {}
+    for prefix, mod, seed in ((P.CKPT_PREFIXES["unet"], VideoUNet(ucfg), 1), (P.CKPT_PREFIXES["controlnet"], ControlNet(ucfg), 2),
+                              (P.CKPT_PREFIXES["decoder"], VideoDecoder(vcfg), 3)):
+        sd.update({prefix + k: v.contiguous() for k, v in init_by_name(mod.spec(), seed=seed).items()})
+    sd["conditioner.embedders.0.dummy"] = torch.zeros(1)            # keys of parts that stay on the reference side are ignored
+    path = str(tmp_path / "model.safetensors")
+    save_file(sd, path)
+    unet, cnet, dec = P.load_streamingsvd_checkpoint(path, device="cpu", unet_cfg=ucfg, vae_cfg=vcfg)
+    assert unet.prepared and cnet.prepared
+    sd.pop(P.CKPT_PREFIXES["unet"] + "out.2.weight")
+    with pytest.raises(RuntimeError):
+        P.load_streamingsvd_checkpoint(sd, device="cpu", unet_cfg=ucfg, vae_cfg=vcfg)
+    pipe = P.StreamingPipeline(unet, cnet, dec)
+    with pytest.raises(NotImplementedError):
+        pipe.image_to_video(torch.zeros(64, 64, 3, dtype=torch.uint8), 25)
+    with pytest.raises(NotImplementedError):
+        pipe.interpolate_video([], 10)
