@@ -91,6 +91,8 @@ typedef struct svd_gemm_args {
     int32_t tile_cfg;
     int32_t dtype;                        /* SVD_DTYPE_BF16 | SVD_DTYPE_F16 : A, W, R, S and 16-bit outputs */
     uint64_t* dbg_cycles;                 /* optional (NULL in production): 8 x u64 phase cycle counters of block 0 / wave 0 */
+    int32_t pad_mode;                     /* conv, stride 2: 0 = zero padding 1 on every side; 1 = F.pad (0,1,0,1) then padding 0
+                                             (Downsample of the VAE encoder, sgm/modules/diffusionmodules/model.py:73-92) */
 } svd_gemm_args;
 
 int svd_gemm(const svd_gemm_args* args, svd_stream_t stream);

@@ -68,7 +68,9 @@ def tiny_sampler_inputs():
 
 def tiny_vae_inputs():
     g = _gen(99)
-    return dict(z=torch.randn(TINY_VAE["T"], 4, TINY_VAE["h"], TINY_VAE["w"], generator=g))
+    z = torch.randn(TINY_VAE["T"], 4, TINY_VAE["h"], TINY_VAE["w"], generator=g)
+    # encoder input: 2 frames of 64x128 pixels in [-1, 1]  (2 levels -> latent 32x64: 2048 tokens for the mid attention)
+    return dict(z=z, x_enc=torch.rand(2, 3, 64, 128, generator=g) * 2 - 1)
 
 
 # ---- I2VGen-XL enhancer (row A12): tiny configuration of code/i2v_enhance/unet_i2vgen_xl.py:188-211 ----

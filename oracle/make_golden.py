@@ -138,6 +138,26 @@ def main():
     assert e <= TOL, e
     torch.save({"out": ref_d.clone()}, os.path.join(OUT, "vae_tiny.pt"))
 
+    # ---------------- VAE encoder (conditioner side) ----------------
+    from models.svd.sgm.modules.diffusionmodules.model import Encoder
+    from streamingt2v_amd.temporal_ae import Encoder as OurEnc
+    enc = Encoder(ch=TINY_VAE["ch"], out_ch=3, ch_mult=TINY_VAE["ch_mult"], num_res_blocks=TINY_VAE["num_res_blocks"], attn_resolutions=[],
+                  dropout=0.0, in_channels=3, resolution=256, z_channels=4, double_z=True, attn_type="vanilla").eval()
+    sd_e = load_by_name(enc, seed=4)
+    assert dict(OurEnc(VaeConfig(TINY_VAE["ch"], TINY_VAE["ch_mult"], TINY_VAE["num_res_blocks"])).spec()) == dict(spec_of(enc)), \
+        "Encoder spec != reference state_dict"
+    xe = tiny_vae_inputs()["x_enc"]
+    ref_e = enc(xe)
+    ora_e = O.vae_encoder(sd_e, O.VaeCfg(TINY_VAE["ch"], TINY_VAE["ch_mult"], TINY_VAE["num_res_blocks"]), xe)
+    e = maxerr(ref_e, ora_e)
+    print(f"[vae encoder] ref-vs-oracle max abs err {e:.3e} (|out| std {ref_e.std():.3f})")
+    assert e <= TOL, e
+    torch.save({"out": ref_e.clone()}, os.path.join(OUT, "vae_enc_tiny.pt"))
+    with torch.device("meta"):
+        fenc = Encoder(ch=128, out_ch=3, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3,
+                       resolution=256, z_channels=4, double_z=True, attn_type="vanilla")
+    assert dict(OurEnc(VaeConfig()).spec()) == dict(spec_of(fenc)), "full encoder spec mismatch"
+
     # full-size specs (meta device): key/shape equality of the shipped configuration
     with torch.device("meta"):
         from oracle.cases import full_unet_kwargs

@@ -311,6 +311,22 @@ def _ae_attn(sd, p, x):
     return x + F.conv2d(o, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
 
 
+def vae_encoder(sd, cfg, x):
+    """Encoder.forward, diffusionmodules/model.py:567-601 (Downsample :73-92: F.pad (0,1,0,1) + stride-2 conv, padding 0).
+    x [n, 3, H, W] -> moments [n, 2 * z_channels, H/8, W/8]."""
+    h = F.conv2d(x, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    for lvl in range(len(cfg.ch_mult)):
+        for b in range(cfg.nrb):
+            h = _ae_resnet(sd, f"down.{lvl}.block.{b}.", h)
+        if lvl != len(cfg.ch_mult) - 1:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"down.{lvl}.downsample.conv.weight"], sd[f"down.{lvl}.downsample.conv.bias"], stride=2)
+    h = _ae_resnet(sd, "mid.block_1.", h)
+    h = _ae_attn(sd, "mid.attn_1.", h)
+    h = _ae_resnet(sd, "mid.block_2.", h)
+    h = F.silu(_gn(sd, "norm_out", h, 1e-6))
+    return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
 def video_decoder(sd, cfg, z, timesteps):
     """VideoDecoder / Decoder.forward, diffusionmodules/model.py:715-748 + temporal_ae.py:291-347, AE3DConv :99-105."""
     T = timesteps

@@ -69,6 +69,7 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
             if (a.K != 9 * a.cin || a.hin <= 0 || a.win <= 0 || a.hout <= 0 || a.wout <= 0) return SVD_EINVAL;
             if ((a.stride != 1 && a.stride != 2) || (a.ups != 0 && a.ups != 1)) return SVD_EINVAL;
             if (a.M % (a.hout * a.wout) != 0) return SVD_EINVAL;
+            if (a.pad_mode != 0 && (a.pad_mode != 1 || a.stride != 2)) return SVD_EINVAL;
             if (a.ups && (a.stride != 1 || a.hout > 2 * a.hin || a.hout < 2 * a.hin - 1 || a.wout > 2 * a.win || a.wout < 2 * a.win - 1))
                 return SVD_EINVAL;
         } else if (a.a_mode == SVD_A_TEMPORAL3) {

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""), "libsvdhip.so"))   # probe: developer build with a reduced tile table
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
@@ -54,6 +54,7 @@ class GemmArgs(C.Structure):
         ("tile_cfg", C.c_int32),
         ("dtype", C.c_int32),
         ("dbg_cycles", C.c_void_p),
+        ("pad_mode", C.c_int32),
     ]
 
 

@@ -98,6 +98,7 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
         args.cin, args.hin, args.win = conv["cin"], conv["hin"], conv["win"]
         args.hout, args.wout = conv["hout"], conv["wout"]
         args.stride, args.ups = conv.get("stride", 1), conv.get("ups", 0)
+        args.pad_mode = conv.get("pad_mode", 0)
         assert a.shape[0] == conv["frames"] * conv["hin"] * conv["win"]
     elif temporal is not None:
         M = a.shape[0]

@@ -211,3 +211,123 @@ class AutoencodingEngineDecoder:
 
     def decode(self, z, **kwargs):
         return self.decoder.forward(z, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# VAE encoder (first piece): what the reference's conditioner runs on the conditioning frame to obtain the
+# `concat` latents (VideoPredictionEmbedderWithEncoder -> first_stage_model.encoder, config.yaml:205-238).
+class AEResBlock2D:
+    """ResnetBlock with temb=None (diffusionmodules/model.py:94-151): GN(1e-6)+SiLU -> conv -> GN+SiLU -> conv (+ 1x1 shortcut)."""
+
+    def __init__(self, prefix, cin, cout):
+        self.p, self.cin, self.cout = prefix, cin, cout
+
+    def spec(self, s):
+        p, ci, co = self.p, self.cin, self.cout
+        s.add(p + "norm1.weight", ci); s.add(p + "norm1.bias", ci)
+        s.add(p + "conv1.weight", co, ci, 3, 3); s.add(p + "conv1.bias", co)
+        s.add(p + "norm2.weight", co); s.add(p + "norm2.bias", co)
+        s.add(p + "conv2.weight", co, co, 3, 3); s.add(p + "conv2.bias", co)
+        if ci != co:
+            s.add(p + "nin_shortcut.weight", co, ci, 1, 1); s.add(p + "nin_shortcut.bias", co)
+
+    def prepare(self, sd, dev):
+        g = lambda k: sd[self.p + k]
+        Fv = lambda k: _dev_f32(g(k), dev)
+        self.n1, self.n2 = (Fv("norm1.weight"), Fv("norm1.bias")), (Fv("norm2.weight"), Fv("norm2.bias"))
+        self.w1, self.b1 = _dev_bf16(pack_conv3x3(g("conv1.weight")), dev), Fv("conv1.bias")
+        self.w2, self.b2 = _dev_bf16(pack_conv3x3(g("conv2.weight")), dev), Fv("conv2.bias")
+        if self.cin != self.cout:
+            self.ws, self.bs = _dev_bf16(g("nin_shortcut.weight")[:, :, 0, 0], dev), Fv("nin_shortcut.bias")
+
+    def forward(self, x, F, H, W):
+        pix = H * W
+        h = ops.groupnorm(x, F, pix, *self.n1, 1e-6, silu=True)
+        h = ops.gemm(h, self.w1, bias=self.b1, conv=dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F))
+        h = ops.groupnorm(h, F, pix, *self.n2, 1e-6, silu=True)
+        skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
+        return ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F))
+
+
+class _DownsampleAsym(_Conv):
+    """Downsample (diffusionmodules/model.py:73-92): F.pad(x, (0,1,0,1)) then 3x3 conv, stride 2, padding 0."""
+
+    def __init__(self, prefix, ch):
+        super().__init__(prefix, ch, ch, stride=2)
+
+    def forward(self, x, F, H, W, **kw):
+        ho, wo = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
+        cv = dict(cin=self.cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=2, ups=0, pad_mode=1, frames=F)
+        return ops.gemm(x, self.w, bias=self.b, conv=cv, **kw), ho, wo
+
+
+class Encoder:
+    """sgm Encoder (diffusionmodules/model.py:487-601), encoder_config of config.yaml:222-238: ``forward(x [n,3,H,W] in [-1,1])``
+    -> moments [n, 2*z_channels, H/8, W/8] fp32 (mean | logvar); state_dict keys as under ``first_stage_model.encoder.``."""
+
+    def __init__(self, cfg=None, in_channels=3, double_z=True):
+        cfg = cfg or VaeConfig()
+        self.cfg, self.in_channels = cfg, in_channels
+        self.zc = (2 if double_z else 1) * cfg.z_channels
+        self.conv_in = _Conv("conv_in.", in_channels, cfg.ch)
+        self.down = []
+        block_in = cfg.ch
+        for lvl, mult in enumerate(cfg.ch_mult):
+            blocks = []
+            for b in range(cfg.num_res_blocks):
+                blocks.append(AEResBlock2D(f"down.{lvl}.block.{b}.", block_in, cfg.ch * mult))
+                block_in = cfg.ch * mult
+            ds = _DownsampleAsym(f"down.{lvl}.downsample.conv.", block_in) if lvl != len(cfg.ch_mult) - 1 else None
+            self.down.append((blocks, ds))
+        self.mid_block_1 = AEResBlock2D("mid.block_1.", block_in, block_in)
+        self.mid_attn_1 = AEAttnBlock("mid.attn_1.", block_in)
+        self.mid_block_2 = AEResBlock2D("mid.block_2.", block_in, block_in)
+        self.final_ch = block_in
+        self.conv_out = _Conv("conv_out.", block_in, self.zc)
+        self.prepared = False
+
+    def _modules(self):
+        yield self.conv_in
+        for blocks, ds in self.down:
+            yield from blocks
+            if ds is not None:
+                yield ds
+        yield self.mid_block_1
+        yield self.mid_attn_1
+        yield self.mid_block_2
+        yield self.conv_out
+
+    def spec(self):
+        s = Spec()
+        for m in self._modules():
+            m.spec(s)
+        s.add("norm_out.weight", self.final_ch); s.add("norm_out.bias", self.final_ch)
+        return s
+
+    def load_state_dict(self, sd, device="cuda", prefix=""):
+        if prefix:
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        check_state_dict(self.spec(), sd)
+        for m in self._modules():
+            m.prepare(sd, device)
+        self.no = (_dev_f32(sd["norm_out.weight"], device), _dev_f32(sd["norm_out.bias"], device))
+        self.device, self.prepared = device, True
+        return self
+
+    def forward(self, x):
+        n, _, H, W = x.shape
+        h = ops.nchw_to_tokens(x.float().contiguous(), None, None, 32)
+        h, H, W = self.conv_in.forward(h, n, H, W)
+        for blocks, ds in self.down:
+            for b in blocks:
+                h = b.forward(h, n, H, W)
+            if ds is not None:
+                h, H, W = ds.forward(h, n, H, W)
+        h = self.mid_block_1.forward(h, n, H, W)
+        h = self.mid_attn_1.forward(h, n, H, W)
+        h = self.mid_block_2.forward(h, n, H, W)
+        h = ops.groupnorm(h, n, H * W, *self.no, 1e-6, silu=True)
+        h, _, _ = self.conv_out.forward(h, n, H, W, out_f32=True)
+        return ops.tokens_to_nchw(h, self.zc, n, H, W)
+
+    __call__ = forward

@@ -253,3 +253,16 @@ def test_range_quantisation_bit_exact():
     g = torch.Generator(); g.manual_seed(7)
     big = (torch.rand(3, 3, 576, 1024, generator=g) * 2.2 - 1.1).clamp(-1, 1)        # full frame size incl. saturated values
     assert torch.equal(StreamingSVD.to_uint8_video(big.cuda()).cpu(), frames_to_uint8(big))
+
+
+def test_vae_encoder_vs_reference_golden(elem, golden_dir):
+    """The conditioner's VAE encoder (sgm Encoder, asymmetric-pad stride-2 convs) on the HIP kernels vs the reference output."""
+    from oracle import cases
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import Encoder, VaeConfig
+    tv = cases.TINY_VAE
+    enc = Encoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]))
+    enc.load_state_dict(init_by_name(enc.spec(), seed=4), device="cuda")
+    out = enc(cases.tiny_vae_inputs()["x_enc"].cuda())
+    gold = torch.load(os.path.join(golden_dir, "vae_enc_tiny.pt"))["out"]
+    report("VAE Encoder vs reference", out, gold)

@@ -117,3 +117,15 @@ def test_range_oracle_matches_reference_bytes(golden_dir):
     gold = torch.load(os.path.join(golden_dir, "range_tiny.pt"))["u8"]
     out = frames_to_uint8(cases.range_inputs())
     assert out.dtype == torch.uint8 and torch.equal(out, gold)
+
+
+def test_vae_encoder_oracle_matches_reference(golden_dir):
+    """sgm Encoder (the conditioner's VAE encoder) restatement vs the reference module's output."""
+    torch.set_grad_enabled(False)
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import Encoder, VaeConfig
+    tv = cases.TINY_VAE
+    sd = init_by_name(Encoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])).spec(), seed=4)
+    out = O.vae_encoder(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), cases.tiny_vae_inputs()["x_enc"])
+    gold = torch.load(os.path.join(golden_dir, "vae_enc_tiny.pt"))["out"]
+    assert out.shape == gold.shape == (2, 8, 32, 64) and (out - gold).abs().max().item() <= TOL
