@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const svd_bf16* _
 
 // I2VGenXLTransformerTemporalEncoder on the 4-channel image latents (unet_i2vgen_xl.py:110-160, called at :700-709): per pixel a
 // sequence of F frames x 4 channels:  x += to_out(attn(LN(x)))  (2 heads x 4, q/k/v without bias) ;  x += W2 gelu(W1 x + b1) + b2.
-// One wave per (batch, pixel); lane = frame (F <= 64); keys/values travel by cross-lane reads.  Everything fp32.
+// One wave per (batch, pixel); a lane owns frames `lane` and `lane + 64` (F <= 128: the 38-frame windows use one slot, the
+// single 100-frame window of the no-blending mode two); keys/values travel by cross-lane reads.  Everything fp32.
 // params: ln_w[4] ln_b[4] wq[8][4] wk[8][4] wv[8][4] wo[4][8] bo[4] w1[16][4] b1[16] w2[4][16] b2[4]   (288 floats)
 template <class E>
 __global__ __launch_bounds__(256) void i2v_image_encoder_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const float* __restrict__ prm,
@@ -45,80 +46,100 @@ __global__ __launch_bounds__(256) void i2v_image_encoder_kernel(const svd_bf16* 
     const float *ln_w = P, *ln_b = P + 4, *wq = P + 8, *wk = P + 40, *wv = P + 72, *wo = P + 104, *bo = P + 136, *w1 = P + 140,
                 *b1 = P + 204, *w2 = P + 220, *b2 = P + 284;
     const int lane = threadIdx.x & 63;
+    const int nslot = (frames + 63) >> 6;                       // 1 or 2 (wave-uniform)
     const int64_t nprob = (int64_t)batch * pix;
     for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
         const int b = (int)(prob / pix), p = (int)(prob % pix);
-        const bool act = lane < frames;
-        const int fr = act ? lane : frames - 1;
-        const int64_t row = ((int64_t)b * frames + fr) * pix + p;
-        const uint2 u = *(const uint2*)(X + row * ldx);
-        float x[4] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y)};
-        // LayerNorm(4), eps 1e-5
-        const float mean = 0.25f * ((x[0] + x[1]) + (x[2] + x[3]));
-        float var = 0.f, n[4];
+        float x[2][4], q[2][8], k[2][8], v[2][8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { n[i] = x[i] - mean; var += n[i] * n[i]; }
-        const float rstd = rsqrtf(0.25f * var + 1e-5f);
+        for (int sl = 0; sl < 2; ++sl) {
+            const int fr0 = lane + 64 * sl;
+            const int fr = fr0 < frames ? fr0 : frames - 1;
+            const int64_t row = ((int64_t)b * frames + fr) * pix + p;
+            const uint2 u = *(const uint2*)(X + row * ldx);
+            x[sl][0] = E::lo(u.x); x[sl][1] = E::hi(u.x); x[sl][2] = E::lo(u.y); x[sl][3] = E::hi(u.y);
+            // LayerNorm(4), eps 1e-5
+            const float mean = 0.25f * ((x[sl][0] + x[sl][1]) + (x[sl][2] + x[sl][3]));
+            float var = 0.f, n[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) n[i] = n[i] * rstd * ln_w[i] + ln_b[i];
-        float q[8], k[8], v[8];
+            for (int i = 0; i < 4; ++i) { n[i] = x[sl][i] - mean; var += n[i] * n[i]; }
+            const float rstd = rsqrtf(0.25f * var + 1e-5f);
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            q[o] = k[o] = v[o] = 0.f;
+            for (int i = 0; i < 4; ++i) n[i] = n[i] * rstd * ln_w[i] + ln_b[i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { q[o] += wq[o * 4 + i] * n[i]; k[o] += wk[o * 4 + i] * n[i]; v[o] += wv[o * 4 + i] * n[i]; }
+            for (int o = 0; o < 8; ++o) {
+                q[sl][o] = k[sl][o] = v[sl][o] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    q[sl][o] += wq[o * 4 + i] * n[i]; k[sl][o] += wk[o * 4 + i] * n[i]; v[sl][o] += wv[o * 4 + i] * n[i];
+                }
+            }
         }
         // attention over the frames: two heads of dim 4, scale 4^-0.5; two passes (max, then sum) keep it simple and exact
-        float att[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float mx = -INFINITY;
-            for (int j = 0; j < frames; ++j) {
-                float s = 0.f;
+        for (int sl = 0; sl < 2; ++sl) {
+            if (sl >= nslot) break;
+            float att[8];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) s += q[h * 4 + d] * __shfl(k[h * 4 + d], j, 64);
-                mx = fmaxf(mx, s * 0.5f);
+            for (int h = 0; h < 2; ++h) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int nj = frames - 64 * ks < 64 ? frames - 64 * ks : 64;
+                    for (int j = 0; j < nj; ++j) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) s += q[sl][h * 4 + d] * __shfl(k[ks][h * 4 + d], j, 64);
+                        mx = fmaxf(mx, s * 0.5f);
+                    }
+                }
+                float l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int nj = frames - 64 * ks < 64 ? frames - 64 * ks : 64;
+                    for (int j = 0; j < nj; ++j) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) s += q[sl][h * 4 + d] * __shfl(k[ks][h * 4 + d], j, 64);
+                        const float pj = __expf(s * 0.5f - mx);
+                        l += pj;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) o[d] += pj * __shfl(v[ks][h * 4 + d], j, 64);
+                    }
+                }
+                const float inv = 1.f / l;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) att[h * 4 + d] = o[d] * inv;
             }
-            float l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < frames; ++j) {
-                float s = 0.f;
+            float xo[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) s += q[h * 4 + d] * __shfl(k[h * 4 + d], j, 64);
-                const float pj = __expf(s * 0.5f - mx);
-                l += pj;
+            for (int i = 0; i < 4; ++i) {
+                float a = bo[i];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) o[d] += pj * __shfl(v[h * 4 + d], j, 64);
+                for (int o = 0; o < 8; ++o) a += wo[i * 8 + o] * att[o];
+                xo[i] = x[sl][i] + a;
             }
-            const float inv = 1.f / l;
+            float hdn[16];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) att[h * 4 + d] = o[d] * inv;
-        }
+            for (int o = 0; o < 16; ++o) {
+                float a = b1[o];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float a = bo[i];
+                for (int i = 0; i < 4; ++i) a += w1[o * 4 + i] * xo[i];
+                hdn[o] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));
+            }
 #pragma unroll
-            for (int o = 0; o < 8; ++o) a += wo[i * 8 + o] * att[o];
-            x[i] += a;
-        }
-        float hdn[16];
+            for (int i = 0; i < 4; ++i) {
+                float a = b2[i];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            float a = b1[o];
+                for (int o = 0; o < 16; ++o) a += w2[i * 16 + o] * hdn[o];
+                xo[i] += a;
+            }
+            const int fr = lane + 64 * sl;
+            if (fr < frames) {  // fp32 NCHW [(b f), 4, pix]: the per-step sample is concatenated to it by svd_nchw_to_tokens
+                float* y = Y + ((int64_t)b * frames + fr) * 4 * pix + p;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a += w1[o * 4 + i] * x[i];
-            hdn[o] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float a = b2[i];
-#pragma unroll
-            for (int o = 0; o < 16; ++o) a += w2[i * 16 + o] * hdn[o];
-            x[i] += a;
-        }
-        if (act) {      // fp32 NCHW [(b f), 4, pix]: the per-step sample is concatenated to it by svd_nchw_to_tokens
-            float* y = Y + ((int64_t)b * frames + fr) * 4 * pix + p;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[(int64_t)i * pix] = x[i];
+                for (int i = 0; i < 4; ++i) y[(int64_t)i * pix] = xo[i];
+            }
         }
     }
 }
@@ -157,7 +178,7 @@ extern "C" int svd_adaptive_avgpool_tokens(const svd_bf16* X, int64_t ldx, svd_b
 
 extern "C" int svd_i2v_image_temporal_encoder(const svd_bf16* X, int64_t ldx, const float* params, float* Y, int32_t batch,
                                               int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream) {
-    if (!X || !params || !Y || batch <= 0 || frames <= 0 || frames > 64 || pix <= 0) return SVD_EINVAL;
+    if (!X || !params || !Y || batch <= 0 || frames <= 0 || frames > 128 || pix <= 0) return SVD_EINVAL;
     if (ldx % 4 || ((uintptr_t)X & 7)) return SVD_EINVAL;
     int64_t blocks = ((int64_t)batch * pix + 3) / 4;
     if (blocks > 4096) blocks = 4096;
