@@ -158,6 +158,24 @@ def main():
                        resolution=256, z_channels=4, double_z=True, attn_type="vanilla")
     assert dict(OurEnc(VaeConfig()).spec()) == dict(spec_of(fenc)), "full encoder spec mismatch"
 
+    # cond_frames embedder's encoder: AutoencoderKLModeOnly.encode (encoder + quant_conv, mode of the posterior)
+    from models.svd.sgm.models.autoencoder import AutoencoderKLModeOnly
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder
+    kl = AutoencoderKLModeOnly(embed_dim=4, monitor="val/rec_loss", lossconfig={"target": "torch.nn.Identity"},
+                               ddconfig=dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3,
+                                             ch=TINY_VAE["ch"], ch_mult=list(TINY_VAE["ch_mult"]), num_res_blocks=TINY_VAE["num_res_blocks"],
+                                             attn_resolutions=[], dropout=0.0)).eval()
+    ours_kl = CondFrameEncoder(VaeConfig(TINY_VAE["ch"], TINY_VAE["ch_mult"], TINY_VAE["num_res_blocks"]))
+    sd_k = init_by_name(ours_kl.spec(), seed=6)
+    missing, unexpected = kl.load_state_dict(sd_k, strict=False)
+    assert not unexpected and all(k.startswith(("decoder.", "post_quant_conv.")) for k in missing), (missing[:4], unexpected[:4])
+    ref_k = kl.encode(xe)
+    ora_k = O.cond_frame_encode(sd_k, O.VaeCfg(TINY_VAE["ch"], TINY_VAE["ch_mult"], TINY_VAE["num_res_blocks"]), xe)
+    e = maxerr(ref_k, ora_k)
+    print(f"[cond-frame encoder (KL mode only)] ref-vs-oracle max abs err {e:.3e} (|out| std {ref_k.std():.3f})")
+    assert e <= TOL, e
+    torch.save({"out": ref_k.clone()}, os.path.join(OUT, "cond_enc_tiny.pt"))
+
     # full-size specs (meta device): key/shape equality of the shipped configuration
     with torch.device("meta"):
         from oracle.cases import full_unet_kwargs

@@ -327,6 +327,13 @@ def vae_encoder(sd, cfg, x):
     return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
 
 
+def cond_frame_encode(sd, cfg, x):
+    """AutoencoderKLModeOnly.encode (sgm/models/autoencoder.py:468-490): encoder -> quant_conv -> mode (mean half of the moments)."""
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    m = F.conv2d(vae_encoder(enc, cfg, x), sd["quant_conv.weight"], sd["quant_conv.bias"])
+    return m[:, : m.shape[1] // 2]
+
+
 def video_decoder(sd, cfg, z, timesteps):
     """VideoDecoder / Decoder.forward, diffusionmodules/model.py:715-748 + temporal_ae.py:291-347, AE3DConv :99-105."""
     T = timesteps

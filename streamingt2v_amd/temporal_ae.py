@@ -331,3 +331,51 @@ class Encoder:
         return ops.tokens_to_nchw(h, self.zc, n, H, W)
 
     __call__ = forward
+
+
+class CondFrameEncoder:
+    """AutoencoderKLModeOnly.encode (sgm/models/autoencoder.py:468-490, regulariser DiagonalGaussianRegularizer(sample=False)), the
+    encoder of the conditioner's `cond_frames` embedder (config.yaml:183-214): encoder -> quant_conv (1x1, 8 -> 8) -> mode = the
+    mean half.  state_dict keys ``encoder.*`` + ``quant_conv.*`` (as under ``conditioner.embedders.3.encoder.``; its decoder /
+    post_quant_conv keys are not used by the conditioner and are ignored).  forward(x [n,3,H,W] in [-1,1]) -> [n, 4, H/8, W/8]."""
+
+    def __init__(self, cfg=None):
+        self.enc = Encoder(cfg)
+        self.zc = self.enc.zc
+
+    def spec(self):
+        s = Spec()
+        for n, sh in self.enc.spec():
+            s.add("encoder." + n, *sh)
+        s.add("quant_conv.weight", self.zc, self.zc, 1, 1); s.add("quant_conv.bias", self.zc)
+        return s
+
+    def load_state_dict(self, sd, device="cuda", prefix=""):
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if prefix else dict(sd)
+        sd = {k: v for k, v in sd.items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+        check_state_dict(self.spec(), sd)
+        self.enc.load_state_dict(sd, device=device, prefix="encoder.")
+        w = torch.zeros(self.zc, 32)
+        w[:, : self.zc] = sd["quant_conv.weight"].detach().float()[:, :, 0, 0]
+        self.qw, self.qb = _dev_bf16(w, device), _dev_f32(sd["quant_conv.bias"], device)
+        self.device = device
+        return self
+
+    def forward(self, x):
+        e = self.enc
+        n, _, H, W = x.shape
+        h = ops.nchw_to_tokens(x.float().contiguous(), None, None, 32)
+        h, H, W = e.conv_in.forward(h, n, H, W)
+        for blocks, ds in e.down:
+            for b in blocks:
+                h = b.forward(h, n, H, W)
+            if ds is not None:
+                h, H, W = ds.forward(h, n, H, W)
+        h = e.mid_block_2.forward(e.mid_attn_1.forward(e.mid_block_1.forward(h, n, H, W), n, H, W), n, H, W)
+        h = ops.groupnorm(h, n, H * W, *e.no, 1e-6, silu=True)
+        buf = torch.zeros((n * H * W, 32), dtype=h.dtype, device=h.device)       # moments in channels 0..7, zero padded to K = 32
+        e.conv_out.forward(h, n, H, W, out=buf[:, : self.zc])
+        m = ops.gemm(buf, self.qw, bias=self.qb, out_f32=True)                    # quant_conv
+        return ops.tokens_to_nchw(m, self.zc // 2, n, H, W)                        # mode of the diagonal Gaussian = mean channels
+
+    __call__ = forward

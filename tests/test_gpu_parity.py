@@ -266,3 +266,15 @@ def test_vae_encoder_vs_reference_golden(elem, golden_dir):
     out = enc(cases.tiny_vae_inputs()["x_enc"].cuda())
     gold = torch.load(os.path.join(golden_dir, "vae_enc_tiny.pt"))["out"]
     report("VAE Encoder vs reference", out, gold)
+
+
+def test_cond_frame_encoder_vs_reference_golden(elem, golden_dir):
+    """AutoencoderKLModeOnly.encode of the conditioner's cond_frames embedder (encoder + quant_conv + posterior mode)."""
+    from oracle import cases
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder, VaeConfig
+    tv = cases.TINY_VAE
+    enc = CondFrameEncoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]))
+    enc.load_state_dict(init_by_name(enc.spec(), seed=6), device="cuda")
+    out = enc(cases.tiny_vae_inputs()["x_enc"].cuda())
+    report("cond-frame encoder vs reference", out, torch.load(os.path.join(golden_dir, "cond_enc_tiny.pt"))["out"])

@@ -129,3 +129,14 @@ def test_vae_encoder_oracle_matches_reference(golden_dir):
     out = O.vae_encoder(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), cases.tiny_vae_inputs()["x_enc"])
     gold = torch.load(os.path.join(golden_dir, "vae_enc_tiny.pt"))["out"]
     assert out.shape == gold.shape == (2, 8, 32, 64) and (out - gold).abs().max().item() <= TOL
+
+
+def test_cond_frame_encoder_oracle_matches_reference(golden_dir):
+    torch.set_grad_enabled(False)
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder, VaeConfig
+    tv = cases.TINY_VAE
+    sd = init_by_name(CondFrameEncoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])).spec(), seed=6)
+    out = O.cond_frame_encode(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), cases.tiny_vae_inputs()["x_enc"])
+    gold = torch.load(os.path.join(golden_dir, "cond_enc_tiny.pt"))["out"]
+    assert out.shape == gold.shape == (2, 4, 32, 64) and (out - gold).abs().max().item() <= TOL
