@@ -227,6 +227,10 @@ int svd_ddim_cfg_step(const float* x, const float* pred_uncond, const float* pre
  * (lib/farancia/libimage/iimage.py:35-36).  Bit-exact with the reference. */
 int svd_frames_to_uint8(const float* X, uint8_t* Y, int32_t frames, int32_t pix, svd_stream_t stream);
 
+/* Exact-erf GELU in place on 16-bit rows (nn.GELU of the OpenCLIP ViT-H/14 MLP inside FrozenOpenCLIPImageEmbedder,
+ * models/svd/sgm/modules/encoders/modules.py:574-732 -> open_clip transformer.py ResidualAttentionBlock.mlp). */
+int svd_gelu_rows(svd_bf16* X, int64_t ldx, int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,6 +177,21 @@ __global__ __launch_bounds__(256) void frames_to_uint8_kernel(const float* __res
     }
 }
 
+// exact-erf GELU in place on 16-bit tokens (nn.GELU of the OpenCLIP vision tower's MLP; the UNets use the fused GEGLU epilogue)
+template <class E>
+__global__ __launch_bounds__(256) void gelu_rows_kernel(svd_bf16* __restrict__ X, int64_t ldx, int64_t rows, int octets) {
+    const int64_t total = rows * octets;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / octets; const int o = (int)(i - r * octets);
+        uint4* px = (uint4*)(X + r * ldx + o * 8);
+        const uint4 u = *px;
+        uint4 w;
+        w.x = E::pack(gelu_erf_f(E::lo(u.x)), gelu_erf_f(E::hi(u.x))); w.y = E::pack(gelu_erf_f(E::lo(u.y)), gelu_erf_f(E::hi(u.y)));
+        w.z = E::pack(gelu_erf_f(E::lo(u.z)), gelu_erf_f(E::hi(u.z))); w.w = E::pack(gelu_erf_f(E::lo(u.w)), gelu_erf_f(E::hi(u.w)));
+        *px = w;
+    }
+}
+
 }  // namespace
 
 extern "C" int svd_nchw_to_tokens(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
@@ -262,5 +277,15 @@ extern "C" int svd_frames_to_uint8(const float* X, uint8_t* Y, int32_t frames, i
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(frames_to_uint8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, Y, total, pix);
     SVD_CHECK_LAUNCH("frames_to_uint8");
+    return SVD_OK;
+}
+
+extern "C" int svd_gelu_rows(svd_bf16* X, int64_t ldx, int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream) {
+    if (!X || rows <= 0 || channels <= 0 || channels % 8 || ldx % 8 || ((uintptr_t)X & 15)) return SVD_EINVAL;
+    int64_t blocks = (rows * (channels / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gelu_rows_kernel<E>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, rows,
+                                                 channels / 8));
+    SVD_CHECK_LAUNCH("gelu_rows");
     return SVD_OK;
 }

@@ -19,7 +19,7 @@ SYMBOLS = [
     "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_layernorm",
     "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32",
     "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
-    "svd_attn_cross_d64", "svd_adaptive_avgpool_tokens", "svd_i2v_image_temporal_encoder", "svd_ddim_cfg_step", "svd_frames_to_uint8",
+    "svd_attn_cross_d64", "svd_adaptive_avgpool_tokens", "svd_i2v_image_temporal_encoder", "svd_ddim_cfg_step", "svd_frames_to_uint8", "svd_gelu_rows",
 ]
 
 A_PLAIN, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
@@ -99,6 +99,7 @@ def _load():
     lib.svd_i2v_image_temporal_encoder.argtypes = [vp, i64, vp, vp, i32, i32, i32, i32, vp]
     lib.svd_ddim_cfg_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, i32, vp]
     lib.svd_frames_to_uint8.argtypes = [vp, vp, i32, i32, vp]
+    lib.svd_gelu_rows.argtypes = [vp, i64, i64, i32, i32, vp]
     for s in SYMBOLS:
         fn = getattr(lib, s)
         if s not in ("svd_last_error", "svd_groupnorm_partial_elems"):

@@ -341,3 +341,10 @@ def frames_to_uint8(frames):
     out = torch.empty((F_, H, W, 3), dtype=torch.uint8, device=frames.device)
     check(_lib.svd_frames_to_uint8(_p(frames), _p(out), F_, H * W, _stream()), "svd_frames_to_uint8")
     return out
+
+
+def gelu_(x):
+    """exact-erf GELU in place on a [rows, C] 16-bit token tensor."""
+    rows, ld = _rows_ld(x)
+    check(_lib.svd_gelu_rows(_p(x), ld, rows, x.shape[1], _dt(x), _stream()), "svd_gelu_rows")
+    return x

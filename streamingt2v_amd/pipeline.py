@@ -25,7 +25,8 @@ DEFAULTS = dict(num_frames=200, out_fps=24, chunk_size=38, overlap_size=12, use_
                 negative_prompt="Distorted, blurry, discontinuous, Ugly, blurry, low resolution, motionless, static, disfigured, "
                                 "disconnected limbs, Ugly faces, incomplete arms")
 
-CKPT_PREFIXES = dict(unet="model.diffusion_model.", controlnet="controlnet.", decoder="first_stage_model.decoder.")
+CKPT_PREFIXES = dict(unet="model.diffusion_model.", controlnet="controlnet.", decoder="first_stage_model.decoder.",
+                     clip="conditioner.embedders.0.open_clip.model.", cond_encoder="conditioner.embedders.3.encoder.")
 
 
 def load_streamingsvd_checkpoint(path_or_state_dict, device="cuda", unet_cfg=None, vae_cfg=None):
@@ -46,6 +47,18 @@ def load_streamingsvd_checkpoint(path_or_state_dict, device="cuda", unet_cfg=Non
     cnet = ControlNet(cfg).load_state_dict(sd, device=device, prefix=CKPT_PREFIXES["controlnet"])
     dec = VideoDecoder(vae_cfg or VaeConfig()).load_state_dict(sd, device=device, prefix=CKPT_PREFIXES["decoder"])
     return unet, cnet, dec
+
+
+def load_conditioner(state_dict, device="cuda", clip_cfg=None, vae_cfg=None, num_frames=25, generator=None):
+    """The stage-1 conditioner from the same checkpoint: OpenCLIP ViT-H/14 image tower (``conditioner.embedders.0.open_clip.model.
+    visual.*``) + cond-frame encoder (``conditioner.embedders.3.encoder.{encoder,quant_conv}.*``) -> conditioner.SVDConditioner.
+    The text tower / logit_scale keys of open_clip and the embedder's decoder keys are ignored (never used by the reference)."""
+    from .clip_vision import ClipVisionConfig, OpenCLIPVisionTower
+    from .conditioner import SVDConditioner
+    from .temporal_ae import CondFrameEncoder, VaeConfig
+    clip = OpenCLIPVisionTower(clip_cfg or ClipVisionConfig()).load_state_dict(state_dict, device=device, prefix=CKPT_PREFIXES["clip"])
+    enc = CondFrameEncoder(vae_cfg or VaeConfig()).load_state_dict(state_dict, device=device, prefix=CKPT_PREFIXES["cond_encoder"])
+    return SVDConditioner(clip, enc, num_frames=num_frames, generator=generator)
 
 
 def num_autoregressive_generations(num_frames, frames_per_chunk=25, num_conditional_frames=7):

@@ -278,3 +278,65 @@ def test_cond_frame_encoder_vs_reference_golden(elem, golden_dir):
     enc.load_state_dict(init_by_name(enc.spec(), seed=6), device="cuda")
     out = enc(cases.tiny_vae_inputs()["x_enc"].cuda())
     report("cond-frame encoder vs reference", out, torch.load(os.path.join(golden_dir, "cond_enc_tiny.pt"))["out"])
+
+
+def test_clip_vision_tower_vs_oracle(elem):
+    """OpenCLIP ViT image tower (head dim 80 -> per-head GEMM attention with padded heads and masked pad tokens) vs its CPU
+    restatement (open_clip is not vendored: parity unpinned, see oracle/clip_oracle.py); tiny: width 320, 4 heads of 80, 2 layers."""
+    from oracle.clip_oracle import vision_tower
+    from streamingt2v_amd.clip_vision import ClipVisionConfig, OpenCLIPVisionTower
+    from streamingt2v_amd.params import init_by_name
+    cfg = ClipVisionConfig(width=320, layers=2, heads=4, patch_size=14, image_size=56, embed_dim=64)
+    tower = OpenCLIPVisionTower(cfg)
+    sd = init_by_name(tower.spec(), seed=8)
+    tower.load_state_dict(sd, device="cuda")
+    g = torch.Generator(); g.manual_seed(3)
+    img = torch.randn(2, 3, 56, 56, generator=g)
+    out = tower(img.cuda())
+    with torch.no_grad():
+        ref = vision_tower(sd, img, cfg.heads, cfg.patch)
+    assert out.shape == ref.shape == (2, 64)
+    report("OpenCLIP vision tower", out[:, None], ref[:, None])
+
+
+def test_native_conditioner_and_front_end_single_chunk(elem):
+    """StreamingPipeline.image_to_video with the NATIVE conditioner (CLIP tower + cond-frame encoder + sinusoid vector) for one chunk:
+    conditioning tensors vs the CPU oracles of their parts, and the decoded uint8 video has the reference's shape/dtype contract."""
+    from oracle import cases, svd_oracle as O
+    from oracle.clip_oracle import vision_tower
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.clip_vision import ClipVisionConfig, OpenCLIPVisionTower
+    from streamingt2v_amd.conditioner import SVDConditioner
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder, VaeConfig, VideoDecoder
+    from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    tu, tv = cases.TINY_UNET, cases.TINY_VAE
+    ucfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"],
+                      channel_mult=tu["channel_mult"], conditioning_embedding_out_channels=tu["cond_embed"])
+    unet, cnet = VideoUNet(ucfg), ControlNet(ucfg)
+    unet.load_state_dict(init_by_name(unet.spec(), seed=1), device="cuda")
+    cnet.load_state_dict(init_by_name(cnet.spec(), seed=2), device="cuda")
+    dec = VideoDecoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]))
+    dec.load_state_dict(init_by_name(dec.spec(), seed=3), device="cuda")
+    ccfg, ecfg = ClipVisionConfig(width=320, layers=2, heads=4, image_size=224, embed_dim=1024), VaeConfig(32, (1, 1, 1, 2), 1)
+    clip, enc = OpenCLIPVisionTower(ccfg), CondFrameEncoder(ecfg)
+    sd_c, sd_e = init_by_name(clip.spec(), seed=8), init_by_name(enc.spec(), seed=9)
+    clip.load_state_dict(sd_c, device="cuda"); enc.load_state_dict(sd_e, device="cuda")
+    T = tu["T"]
+    cond = SVDConditioner(clip, enc, num_frames=T, generator=torch.Generator(device="cuda").manual_seed(5))
+    g = torch.Generator(); g.manual_seed(6)
+    frame = torch.rand(3, 8 * tu["h"], 8 * tu["w"], generator=g) * 2 - 1
+    c, uc = cond(frame.cuda())
+    # parts vs their oracles (same uniform noise regenerated from the same device generator state)
+    noise = torch.rand((1,) + tuple(frame.shape), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda").cpu()
+    with torch.no_grad():
+        ref_cross = vision_tower(sd_c, SVDConditioner.clip_preprocess(frame[None]), ccfg.heads, ccfg.patch)
+        ref_cat = O.cond_frame_encode(sd_e, O.VaeCfg(32, (1, 1, 1, 2), 1), frame[None] + 0.02 * noise)
+    report("conditioner crossattn (CLIP)", c["crossattn"][:1], ref_cross[:, None])
+    report("conditioner concat (VAE mode)", c["concat"][:1], ref_cat)
+    assert c["concat"].shape == (T, 4, tu["h"], tu["w"]) and uc["concat"].abs().sum().item() == 0
+    pipe = P.StreamingPipeline(unet, cnet, dec, conditioner=cond, num_frames_per_chunk=T, num_conditional_frames=tu["Tc"], num_steps=2)
+    pipe.model._generate_initial_chunk.__func__      # chunk 0 path exists
+    frame_u8 = ((frame.permute(1, 2, 0) + 1) * 127.5).clamp(0, 255).to(torch.uint8)
+    video = pipe.image_to_video(frame_u8, num_frames=T)
+    assert video.shape[0] == T and video.shape[3] == 3 and str(video.dtype) == "uint8"

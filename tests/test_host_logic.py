@@ -205,3 +205,58 @@ def test_pipeline_checkpoint_key_map(tmp_path):
         pipe.image_to_video(torch.zeros(64, 64, 3, dtype=torch.uint8), 25)
     with pytest.raises(NotImplementedError):
         pipe.interpolate_video([], 10)
+
+
+def test_clip_vision_spec_is_vit_h_14():
+    """Full-size tower spec: open_clip ViT-H-14 visual (632 M parameters, 257 x 1280 positions, 1024-d embedding)."""
+    import math
+    from streamingt2v_amd.clip_vision import OpenCLIPVisionTower
+    spec = dict(OpenCLIPVisionTower().spec())
+    assert spec["visual.positional_embedding"] == (257, 1280) and spec["visual.proj"] == (1280, 1024)
+    assert spec["visual.transformer.resblocks.31.attn.in_proj_weight"] == (3840, 1280)
+    assert abs(sum(math.prod(s) for s in spec.values()) / 1e6 - 632.1) < 0.5
+
+
+def test_svd_conditioner_assembly_with_stub_towers():
+    """SVDConditioner: shapes, uc zeroing, vector = [fps_id | motion_bucket_id | cond_aug] sinusoids, uniform cond-aug noise."""
+    import torch
+    from oracle import svd_oracle as O
+    from streamingt2v_amd.conditioner import SVDConditioner, sinusoid
+    seen = {}
+
+    def clip(x):
+        seen["clip"] = x
+        return torch.ones(x.shape[0], 1024)
+
+    def enc(x):
+        seen["enc"] = x
+        return torch.full((x.shape[0], 4, x.shape[2] // 8, x.shape[3] // 8), 0.5)
+
+    frame = torch.rand(3, 64, 96) * 2 - 1
+    c, uc = SVDConditioner(clip, enc, num_frames=5, generator=torch.Generator().manual_seed(1))(frame)
+    assert c["crossattn"].shape == (5, 1, 1024) and c["concat"].shape == (5, 4, 8, 12) and c["vector"].shape == (5, 768)
+    assert uc["crossattn"].abs().sum() == 0 and uc["concat"].abs().sum() == 0 and torch.equal(uc["vector"], c["vector"])
+    assert seen["clip"].shape == (1, 3, 224, 224)
+    d = seen["enc"][0] - frame
+    assert d.min() >= 0 and d.max() <= 0.02 + 1e-6                      # uniform [0, 1) * cond_aug, not Gaussian
+    ref = torch.cat([O.timestep_embedding(torch.tensor([v]), 256) for v in (6.0, 127.0, 0.02)], -1)
+    assert torch.allclose(c["vector"][0], ref[0], atol=1e-6)
+    assert torch.allclose(sinusoid([127.0]), O.timestep_embedding(torch.tensor([127.0]), 256), atol=1e-6)
+
+
+def test_conditioner_checkpoint_key_map():
+    """conditioner.* keys of the reference checkpoint -> CLIP tower + cond-frame encoder (strict on the used sub-trees)."""
+    import torch
+    from oracle import cases
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.clip_vision import ClipVisionConfig, OpenCLIPVisionTower
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder, VaeConfig
+    tv = cases.TINY_VAE
+    ccfg, vcfg = ClipVisionConfig(width=320, layers=1, heads=4, image_size=56, embed_dim=1024), VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])
+    sd = {P.CKPT_PREFIXES["clip"] + k: v for k, v in init_by_name(OpenCLIPVisionTower(ccfg).spec(), seed=1).items()}
+    sd.update({P.CKPT_PREFIXES["cond_encoder"] + k: v for k, v in init_by_name(CondFrameEncoder(vcfg).spec(), seed=2).items()})
+    sd[P.CKPT_PREFIXES["clip"] + "logit_scale"] = torch.zeros(())                      # open_clip extras are ignored
+    sd[P.CKPT_PREFIXES["cond_encoder"] + "post_quant_conv.weight"] = torch.zeros(4, 4, 1, 1)
+    cond = P.load_conditioner(sd, device="cpu", clip_cfg=ccfg, vae_cfg=vcfg, num_frames=8)
+    assert cond.T == 8 and cond.clip.device == "cpu"
