@@ -3,7 +3,8 @@ class-token pooling, ln_post after pooling, projection) used by the reference's 
 (code/models/svd/sgm/modules/encoders/modules.py:574-732).  TEST INFRASTRUCTURE ONLY.
 
 open_clip is neither vendored under /root/reference nor installed here, and the reference holds no vectors for it:
-**parity unpinned** -- restated from the published model definition (transformer.py: VisionTransformer, ResidualAttentionBlock with
+**parity unpinned** against open_clip; cross-checked (4.8e-8) against HuggingFace transformers' CLIPVisionModelWithProjection on
+mapped weights (oracle/check_clip_vs_hf.py, tests/test_oracle_golden.py) -- restated from the published model definition (transformer.py: VisionTransformer, ResidualAttentionBlock with
 nn.MultiheadAttention(batch_first=False), nn.GELU, LayerNorm eps 1e-5, no layer scale, no patch dropout at inference)."""
 import torch
 import torch.nn.functional as F

@@ -140,3 +140,12 @@ def test_cond_frame_encoder_oracle_matches_reference(golden_dir):
     out = O.cond_frame_encode(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), cases.tiny_vae_inputs()["x_enc"])
     gold = torch.load(os.path.join(golden_dir, "cond_enc_tiny.pt"))["out"]
     assert out.shape == gold.shape == (2, 4, 32, 64) and (out - gold).abs().max().item() <= TOL
+
+
+def test_clip_oracle_matches_hf_transformers_implementation():
+    """oracle/clip_oracle.py vs HuggingFace's CLIPVisionModelWithProjection on mapped weights (independent implementation of the same
+    ViT; open_clip itself is unavailable -- see oracle/check_clip_vs_hf.py)."""
+    pytest = __import__("pytest")
+    pytest.importorskip("transformers")
+    from oracle import check_clip_vs_hf
+    check_clip_vs_hf.main()
