@@ -327,6 +327,22 @@ def vae_encoder(sd, cfg, x):
     return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
 
 
+def vae_decoder_2d(sd, cfg, z):
+    """Decoder.forward (2-D, no temporal layers), diffusionmodules/model.py:715-748; Upsample :52-70 (nearest 2x + conv)."""
+    h = F.conv2d(z, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    h = _ae_resnet(sd, "mid.block_1.", h)
+    h = _ae_attn(sd, "mid.attn_1.", h)
+    h = _ae_resnet(sd, "mid.block_2.", h)
+    for lvl in reversed(range(len(cfg.ch_mult))):
+        for b in range(cfg.nrb + 1):
+            h = _ae_resnet(sd, f"up.{lvl}.block.{b}.", h)
+        if lvl != 0:
+            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), sd[f"up.{lvl}.upsample.conv.weight"],
+                         sd[f"up.{lvl}.upsample.conv.bias"], padding=1)
+    h = F.silu(_gn(sd, "norm_out", h, 1e-6))
+    return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
 def cond_frame_encode(sd, cfg, x):
     """AutoencoderKLModeOnly.encode (sgm/models/autoencoder.py:468-490): encoder -> quant_conv -> mode (mean half of the moments)."""
     enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}

@@ -379,3 +379,149 @@ class CondFrameEncoder:
         return ops.tokens_to_nchw(m, self.zc // 2, n, H, W)                        # mode of the diagonal Gaussian = mean channels
 
     __call__ = forward
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# 2-D KL autoencoder (LDM / Stable-Diffusion VAE): the arithmetic of sgm's Encoder / Decoder (diffusionmodules/model.py:487-748),
+# which diffusers' AutoencoderKL -- the VAE around the I2VGen-XL enhancer (pipeline_i2vgen_xl.py:384-406, 586-603) -- re-keys.
+class Decoder2D:
+    """sgm Decoder (model.py:603-748): conv_in, mid (res, attn, res), 4 up levels x (num_res_blocks + 1) res blocks + nearest-2x
+    upsample conv, GN + SiLU + conv_out.  forward(z [n, 4, h, w]) -> [n, 3, 8h, 8w] fp32."""
+
+    def __init__(self, cfg=None):
+        cfg = cfg or VaeConfig()
+        self.cfg = cfg
+        nres = len(cfg.ch_mult)
+        block_in = cfg.ch * cfg.ch_mult[-1]
+        self.conv_in = _Conv("conv_in.", cfg.z_channels, block_in)
+        self.mid_block_1 = AEResBlock2D("mid.block_1.", block_in, block_in)
+        self.mid_attn_1 = AEAttnBlock("mid.attn_1.", block_in)
+        self.mid_block_2 = AEResBlock2D("mid.block_2.", block_in, block_in)
+        self.up = {}
+        for lvl in reversed(range(nres)):
+            block_out = cfg.ch * cfg.ch_mult[lvl]
+            blocks = []
+            for b in range(cfg.num_res_blocks + 1):
+                blocks.append(AEResBlock2D(f"up.{lvl}.block.{b}.", block_in, block_out))
+                block_in = block_out
+            self.up[lvl] = (blocks, _Conv(f"up.{lvl}.upsample.conv.", block_in, block_in, ups=1) if lvl != 0 else None)
+        self.final_ch = block_in
+        self.conv_out = _Conv("conv_out.", block_in, cfg.out_ch)
+
+    def _modules(self):
+        yield self.conv_in; yield self.mid_block_1; yield self.mid_attn_1; yield self.mid_block_2
+        for lvl in self.up:
+            blocks, ups = self.up[lvl]
+            yield from blocks
+            if ups is not None:
+                yield ups
+        yield self.conv_out
+
+    def spec(self):
+        s = Spec()
+        for m in self._modules():
+            m.spec(s)
+        s.add("norm_out.weight", self.final_ch); s.add("norm_out.bias", self.final_ch)
+        return s
+
+    def load_state_dict(self, sd, device="cuda", prefix=""):
+        if prefix:
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        check_state_dict(self.spec(), sd)
+        for m in self._modules():
+            m.prepare(sd, device)
+        self.no = (_dev_f32(sd["norm_out.weight"], device), _dev_f32(sd["norm_out.bias"], device))
+        self.device = device
+        return self
+
+    def forward(self, z, clamp=False):
+        n, _, H, W = z.shape
+        h = ops.nchw_to_tokens(z.float().contiguous(), None, None, 32)
+        h, H, W = self.conv_in.forward(h, n, H, W)
+        h = self.mid_block_2.forward(self.mid_attn_1.forward(self.mid_block_1.forward(h, n, H, W), n, H, W), n, H, W)
+        for lvl in self.up:
+            blocks, ups = self.up[lvl]
+            for b in blocks:
+                h = b.forward(h, n, H, W)
+            if ups is not None:
+                h, H, W = ups.forward(h, n, H, W)
+        h = ops.groupnorm(h, n, H * W, *self.no, 1e-6, silu=True)
+        h, _, _ = self.conv_out.forward(h, n, H, W, out_f32=True)
+        return ops.tokens_to_nchw(h, self.cfg.out_ch, n, H, W)
+
+    __call__ = forward
+
+
+def diffusers_vae_to_sgm_keys(sd, n_levels=4):
+    """diffusers AutoencoderKL state_dict (the `vae/` of ali-vilab/i2vgen-xl, pipeline_i2vgen_xl.py:384-406) -> the sgm / LDM key
+    names of Encoder / Decoder2D (same architecture: diffusers' AutoencoderKL is the re-keyed LDM autoencoder; its attention's
+    Linear to_q/to_k/to_v/to_out.0 are the 1x1 convs q/k/v/proj_out).  diffusers is not installed: key names as published in
+    diffusers==0.30.2 (models/autoencoders/vae.py, unet_2d_blocks.py) -- the ARITHMETIC behind them is pinned through the sgm classes."""
+    out = {}
+    for k, v in sd.items():
+        part, _, rest = k.partition(".")
+        if part in ("quant_conv", "post_quant_conv"):
+            out[k] = v
+            continue
+        if part not in ("encoder", "decoder"):
+            continue
+        r = rest
+        r = r.replace("conv_norm_out.", "norm_out.").replace("conv_shortcut.", "nin_shortcut.")
+        r = r.replace("mid_block.resnets.0.", "mid.block_1.").replace("mid_block.resnets.1.", "mid.block_2.")
+        if r.startswith("mid_block.attentions.0."):
+            r = r.replace("mid_block.attentions.0.", "mid.attn_1.").replace("group_norm.", "norm.").replace("to_out.0.", "proj_out.")
+            r = r.replace("to_q.", "q.").replace("to_k.", "k.").replace("to_v.", "v.")
+            if r.endswith("weight") and v.dim() == 2:
+                v = v[:, :, None, None]
+        if r.startswith("down_blocks."):
+            _, i, kind, j, tail = r.split(".", 4)
+            r = f"down.{i}.block.{j}.{tail}" if kind == "resnets" else f"down.{i}.downsample.{tail}"
+        if r.startswith("up_blocks."):
+            _, i, kind, j, tail = r.split(".", 4)
+            lvl = n_levels - 1 - int(i)
+            r = f"up.{lvl}.block.{j}.{tail}" if kind == "resnets" else f"up.{lvl}.upsample.{tail}"
+        out[part + "." + r] = v
+    return out
+
+
+class AutoencoderKL2D:
+    """The 2-D VAE around the enhancer: encode (posterior mode or sample) and decode, scaling_factor 0.18215
+    (pipeline_i2vgen_xl.py:586-603 retrieve_latents(vae.encode(x)) * scaling_factor; :384-406 vae.decode(latents / scaling_factor))."""
+
+    def __init__(self, cfg=None, scaling_factor=0.18215):
+        self.enc, self.dec, self.sf = CondFrameEncoder(cfg), Decoder2D(cfg), scaling_factor
+
+    def spec(self):
+        s = Spec()
+        for n, sh in self.enc.spec():
+            s.add(n, *sh)
+        for n, sh in self.dec.spec():
+            s.add("decoder." + n, *sh)
+        zc = self.dec.cfg.z_channels
+        s.add("post_quant_conv.weight", zc, zc, 1, 1); s.add("post_quant_conv.bias", zc)
+        return s
+
+    def load_state_dict(self, sd, device="cuda", diffusers_keys=False):
+        if diffusers_keys:
+            sd = diffusers_vae_to_sgm_keys(sd, len(self.dec.cfg.ch_mult))
+        check_state_dict(self.spec(), sd)
+        self.enc.load_state_dict(sd, device=device)
+        self.dec.load_state_dict(sd, device=device, prefix="decoder.")
+        zc = self.dec.cfg.z_channels
+        w = torch.zeros(zc, 32)
+        w[:, :zc] = sd["post_quant_conv.weight"].detach().float()[:, :, 0, 0]
+        self.pw, self.pb = _dev_bf16(w, device), _dev_f32(sd["post_quant_conv.bias"], device)
+        self.device = device
+        return self
+
+    def encode_mode(self, x):
+        """x [n, 3, H, W] in [-1, 1] -> scaling_factor * mean of the posterior [n, 4, H/8, W/8]."""
+        return self.enc(x) * self.sf
+
+    def decode(self, latents):
+        """latents [n, 4, h, w] (scaled) -> images [n, 3, 8h, 8w] fp32."""
+        z = latents.float() * (1.0 / self.sf)
+        n, zc, H, W = z.shape
+        t = ops.nchw_to_tokens(z.contiguous(), None, None, 32)
+        t = ops.gemm(t, self.pw, bias=self.pb, out_f32=True)                      # post_quant_conv (1x1)
+        return self.dec(ops.tokens_to_nchw(t, zc, n, H, W))

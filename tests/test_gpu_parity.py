@@ -340,3 +340,36 @@ def test_native_conditioner_and_front_end_single_chunk(elem):
     frame_u8 = ((frame.permute(1, 2, 0) + 1) * 127.5).clamp(0, 255).to(torch.uint8)
     video = pipe.image_to_video(frame_u8, num_frames=T)
     assert video.shape[0] == T and video.shape[3] == 3 and str(video.dtype) == "uint8"
+
+
+def test_decoder_2d_vs_reference_golden(elem, golden_dir):
+    """sgm Decoder (2-D; the arithmetic of the AutoencoderKL decoder used after the enhancer) vs the reference module's output."""
+    from oracle import cases
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import Decoder2D, VaeConfig
+    tv = cases.TINY_VAE
+    dec = Decoder2D(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]))
+    dec.load_state_dict(init_by_name(dec.spec(), seed=7), device="cuda")
+    out = dec(cases.tiny_vae_inputs()["z"][:2].cuda())
+    report("2-D decoder vs reference", out, torch.load(os.path.join(golden_dir, "vae_dec2d_tiny.pt"))["out"])
+
+
+def test_autoencoder_kl_2d_roundtrip_vs_oracle(elem):
+    """AutoencoderKL2D (encoder + quant_conv mode, post_quant_conv + 2-D decoder, scaling 0.18215) vs the oracle pieces."""
+    from oracle import cases, svd_oracle as O
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import AutoencoderKL2D, VaeConfig
+    import torch.nn.functional as F
+    tv = cases.TINY_VAE
+    cfg, ocfg = VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])
+    vae = AutoencoderKL2D(cfg)
+    sd = init_by_name(vae.spec(), seed=12)
+    vae.load_state_dict(sd, device="cuda")
+    x = cases.tiny_vae_inputs()["x_enc"]
+    lat = vae.encode_mode(x.cuda())
+    with torch.no_grad():
+        ref_lat = O.cond_frame_encode(sd, ocfg, x) * 0.18215
+        z = F.conv2d(ref_lat / 0.18215, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+        ref_img = O.vae_decoder_2d({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, ocfg, z)
+    report("AutoencoderKL2D encode (mode)", lat, ref_lat)
+    report("AutoencoderKL2D decode", vae.decode(ref_lat.cuda()), ref_img)

@@ -260,3 +260,41 @@ def test_conditioner_checkpoint_key_map():
     sd[P.CKPT_PREFIXES["cond_encoder"] + "post_quant_conv.weight"] = torch.zeros(4, 4, 1, 1)
     cond = P.load_conditioner(sd, device="cpu", clip_cfg=ccfg, vae_cfg=vcfg, num_frames=8)
     assert cond.T == 8 and cond.clip.device == "cpu"
+
+
+def test_diffusers_vae_key_map_roundtrip():
+    """diffusers AutoencoderKL key names -> sgm names: every key of our spec is produced exactly once with the right shape."""
+    import torch
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import AutoencoderKL2D, VaeConfig, diffusers_vae_to_sgm_keys
+    cfg = VaeConfig(32, (1, 2, 2, 4), 2)
+    vae = AutoencoderKL2D(cfg)
+    sgm = init_by_name(vae.spec(), seed=1)
+
+    def to_diffusers(k, v):
+        part, _, r = k.partition(".")
+        if part in ("quant_conv", "post_quant_conv"):
+            return k, v
+        r = r.replace("norm_out.", "conv_norm_out.").replace("nin_shortcut.", "conv_shortcut.")
+        r = r.replace("mid.block_1.", "mid_block.resnets.0.").replace("mid.block_2.", "mid_block.resnets.1.")
+        if r.startswith("mid.attn_1."):
+            r = r.replace("mid.attn_1.", "mid_block.attentions.0.").replace("proj_out.", "to_out.0.").replace("norm.", "group_norm.")
+            for n in "qkv":
+                r = r.replace(f"attentions.0.{n}.", f"attentions.0.to_{n}.")
+            if r.endswith("weight") and v.dim() == 4:
+                v = v[:, :, 0, 0]
+        if r.startswith("down."):
+            _, i, kind, rest = r.split(".", 3)
+            r = f"down_blocks.{i}.resnets.{rest.split('.', 1)[0]}.{rest.split('.', 1)[1]}" if kind == "block" else f"down_blocks.{i}.downsamplers.0.{rest}"
+        if r.startswith("up."):
+            _, lvl, kind, rest = r.split(".", 3)
+            i = 3 - int(lvl)
+            r = f"up_blocks.{i}.resnets.{rest.split('.', 1)[0]}.{rest.split('.', 1)[1]}" if kind == "block" else f"up_blocks.{i}.upsamplers.0.{rest}"
+        return part + "." + r, v
+
+    dif = dict(to_diffusers(k, v) for k, v in sgm.items())
+    assert "decoder.up_blocks.0.resnets.2.conv1.weight" in dif and "encoder.mid_block.attentions.0.to_q.weight" in dif
+    assert dif["encoder.mid_block.attentions.0.to_q.weight"].dim() == 2
+    back = diffusers_vae_to_sgm_keys(dif, 4)
+    assert set(back) == set(sgm) and all(torch.equal(back[k], sgm[k]) for k in sgm)
+    vae.load_state_dict(dif, device="cpu", diffusers_keys=True)

@@ -149,3 +149,14 @@ def test_clip_oracle_matches_hf_transformers_implementation():
     pytest.importorskip("transformers")
     from oracle import check_clip_vs_hf
     check_clip_vs_hf.main()
+
+
+def test_decoder_2d_oracle_matches_reference(golden_dir):
+    torch.set_grad_enabled(False)
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import Decoder2D, VaeConfig
+    tv = cases.TINY_VAE
+    sd = init_by_name(Decoder2D(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])).spec(), seed=7)
+    out = O.vae_decoder_2d(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), cases.tiny_vae_inputs()["z"][:2])
+    gold = torch.load(os.path.join(golden_dir, "vae_dec2d_tiny.pt"))["out"]
+    assert out.shape == gold.shape and (out - gold).abs().max().item() <= TOL
