@@ -134,6 +134,25 @@ class OpenCLIPVisionTower:
     __call__ = forward
 
 
+def hf_clip_vision_to_openclip_keys(hf_sd, layers, prefix=""):
+    """transformers CLIPVisionModelWithProjection state_dict (``vision_model.*`` + ``visual_projection.weight``: the enhancer's
+    image_encoder, pipeline_i2vgen_xl.py:349-383) -> the open_clip key names this tower is specified in.  Same architecture; the
+    mapping is verified numerically in oracle/check_clip_vs_hf.py."""
+    g = lambda k: hf_sd[prefix + "vision_model." + k]
+    sd = {"visual.class_embedding": g("embeddings.class_embedding"), "visual.positional_embedding": g("embeddings.position_embedding.weight"),
+          "visual.conv1.weight": g("embeddings.patch_embedding.weight"), "visual.proj": hf_sd[prefix + "visual_projection.weight"].t().contiguous(),
+          "visual.ln_pre.weight": g("pre_layrnorm.weight"), "visual.ln_pre.bias": g("pre_layrnorm.bias"),
+          "visual.ln_post.weight": g("post_layernorm.weight"), "visual.ln_post.bias": g("post_layernorm.bias")}
+    for i in range(layers):
+        h, o = f"encoder.layers.{i}.", f"visual.transformer.resblocks.{i}."
+        sd[o + "attn.in_proj_weight"] = torch.cat([g(h + f"self_attn.{n}_proj.weight") for n in "qkv"], 0)
+        sd[o + "attn.in_proj_bias"] = torch.cat([g(h + f"self_attn.{n}_proj.bias") for n in "qkv"], 0)
+        for a, b in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"),
+                     ("mlp.c_proj", "mlp.fc2")):
+            sd[o + a + ".weight"], sd[o + a + ".bias"] = g(h + b + ".weight"), g(h + b + ".bias")
+    return sd
+
+
 # CLIP preprocessing constants (modules.py:612-617); the resize itself (kornia, antialiased bicubic) stays with the caller
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)

@@ -384,7 +384,7 @@ class I2VGenXLUNet:
         x = ops.adaptive_avgpool(x, B, H, W, 32, 32)
         x, h2, w2 = self.il_ctx[1].forward(x, B, 32, 32, silu=True)
         x, h3, w3 = self.il_ctx[2].forward(x, B, h2, w2)                                   # [B*64, cd]
-        img = lin("context_embedding.2", lin("context_embedding.0", ops.to_elem(f32(image_embeddings)), silu=True))           # [B, 4*cd]
+        img = lin("context_embedding.2", lin("context_embedding.0", ops.to_elem(f32(image_embeddings).reshape(B, cd)), silu=True))   # [B, 4*cd]
         text = ops.to_elem(f32(encoder_hidden_states))
         ctx = torch.cat([text, x.view(B, h3 * w3, cd), img.view(B, -1, cd)], 1).contiguous()                                  # [B, 145, cd]
         n_ctx = ctx.shape[1]

@@ -118,9 +118,9 @@ class StreamingPipeline:
     # ------------------------------------------------------------------------------------------ enhancement
     def enhance_video(self, image, video, chunk_size=38, overlap_size=12, strength=0.97, use_randomized_blending=False, **kwargs):
         """Mirror of enhance_video + i2v_enhance_process (inference_i2v.py:192-207, i2v_enhance_interface.py:82-133).
-        enhance_codec must provide: encode_video(frames uint8 [F,H,W,3] resized to 720x1280) -> latents fp32 [1,4,F,90,160];
-        window_conditioning(image uint8, first_frames, n_windows, window_len) -> list of dicts(fps, image_latents, image_embeddings,
-        text), one per window, unconditional half first; decode(latents) -> uint8 frames; and a torch.Generator for the SDEdit noise."""
+        enhance_codec: enhance_codec.EnhanceCodec (native: AutoencoderKL2D + CLIP towers) or any object with encode_video(frames) ->
+        latents [1,4,F,90,160], window_conditioning(images, n_windows, window_len) -> list of dicts(fps, image_latents,
+        image_embeddings, text) with the unconditional half first, noise_like(latents), decode(latents) -> uint8 [F,H,W,3]."""
         if self.enhancer_unet is None or self.enhance_codec is None:
             raise NotImplementedError("enhance_video needs enhancer_unet (I2VGenXLUNet) and enhance_codec (CLIP text/vision towers + "
                                       "AutoencoderKL encode/decode of the I2VGen-XL pipeline; SURVEY.md 8f N4)")
@@ -134,16 +134,15 @@ class StreamingPipeline:
         if use_randomized_blending:
             starts, max_idx = enhance_windows(len(video), chunk_size, overlap_size)
             key_frames = [video[s] for s in starts]                              # 1st frame of every window, enhanced first
-            lat = codec.encode_video(key_frames)
-            conds = codec.window_conditioning(images, [key_frames[0]], 1, len(key_frames))
-            images = codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng))
+            lat = codec.encode_video(key_frames)                                 # one window of len(starts) frames, no overlap
+            conds = codec.window_conditioning(images, 1, len(key_frames))
+            images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng)))
             video = video[:max_idx]
         else:
             starts, chunk_size, overlap_size = [0], len(video), 0
         lat = codec.encode_video(video)
-        conds = codec.window_conditioning(images, [video[s] for s in starts], len(starts), chunk_size)
-        out = enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng)
-        return codec.decode(out)
+        conds = codec.window_conditioning(images, len(starts), chunk_size)
+        return codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng))
 
     def interpolate_video(self, video, dest_num_frames, **kwargs):
         if self.vfi is None:

@@ -361,7 +361,7 @@ class CondFrameEncoder:
         self.device = device
         return self
 
-    def forward(self, x):
+    def forward(self, x, return_moments=False):
         e = self.enc
         n, _, H, W = x.shape
         h = ops.nchw_to_tokens(x.float().contiguous(), None, None, 32)
@@ -376,9 +376,18 @@ class CondFrameEncoder:
         buf = torch.zeros((n * H * W, 32), dtype=h.dtype, device=h.device)       # moments in channels 0..7, zero padded to K = 32
         e.conv_out.forward(h, n, H, W, out=buf[:, : self.zc])
         m = ops.gemm(buf, self.qw, bias=self.qb, out_f32=True)                    # quant_conv
+        if return_moments:
+            return ops.tokens_to_nchw(m, self.zc, n, H, W)                         # [n, 8, h, w]: mean | logvar
         return ops.tokens_to_nchw(m, self.zc // 2, n, H, W)                        # mode of the diagonal Gaussian = mean channels
 
     __call__ = forward
+
+    def sample(self, x, generator=None):
+        """DiagonalGaussianDistribution.sample (diffusers vae.py / sgm distributions): mean + exp(0.5 * clamp(logvar, -30, 20)) * N(0, 1)."""
+        mom = self.forward(x, return_moments=True)
+        mean, logvar = mom.chunk(2, 1)
+        std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+        return mean + std * torch.randn(mean.shape, generator=generator, device=mean.device)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -513,6 +522,10 @@ class AutoencoderKL2D:
         self.pw, self.pb = _dev_bf16(w, device), _dev_f32(sd["post_quant_conv.bias"], device)
         self.device = device
         return self
+
+    def encode_sample(self, x, generator=None):
+        """retrieve_latents(vae.encode(x), generator) * scaling_factor  (pipeline_i2vgen_xl.py:488-489, 586-603)."""
+        return self.enc.sample(x, generator) * self.sf
 
     def encode_mode(self, x):
         """x [n, 3, H, W] in [-1, 1] -> scaling_factor * mean of the posterior [n, 4, H/8, W/8]."""

@@ -373,3 +373,21 @@ def test_autoencoder_kl_2d_roundtrip_vs_oracle(elem):
         ref_img = O.vae_decoder_2d({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, ocfg, z)
     report("AutoencoderKL2D encode (mode)", lat, ref_lat)
     report("AutoencoderKL2D decode", vae.decode(ref_lat.cuda()), ref_img)
+
+
+def test_clip_text_tower_vs_oracle(elem):
+    """CLIPTextModel.last_hidden_state on the HIP kernels (causal mask as the score GEMM's residual, 77 -> 80 padded tokens) vs the
+    oracle that is pinned against transformers' CLIPTextModel."""
+    from oracle.clip_text_oracle import text_tower
+    from streamingt2v_amd.clip_text import ClipTextConfig, CLIPTextTower
+    from streamingt2v_amd.params import init_by_name
+    cfg = ClipTextConfig(vocab_size=1000, hidden_size=256, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4)
+    tower = CLIPTextTower(cfg)
+    sd = init_by_name(tower.spec(), seed=13)
+    tower.load_state_dict(sd, device="cuda")
+    g = torch.Generator(); g.manual_seed(4)
+    ids = torch.randint(0, 1000, (2, 77), generator=g)
+    out = tower(ids)
+    with torch.no_grad():
+        ref = text_tower(sd, ids, cfg.heads)
+    report("CLIP text tower", out.reshape(2, 77, 256), ref)

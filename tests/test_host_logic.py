@@ -298,3 +298,21 @@ def test_diffusers_vae_key_map_roundtrip():
     back = diffusers_vae_to_sgm_keys(dif, 4)
     assert set(back) == set(sgm) and all(torch.equal(back[k], sgm[k]) for k in sgm)
     vae.load_state_dict(dif, device="cpu", diffusers_keys=True)
+
+
+def test_enhance_codec_host_helpers():
+    """frame-position planes (pipeline_i2vgen_xl.py:491-503) and the PIL centre crop (:965-1000) of the enhancer codec."""
+    import numpy as np
+    import PIL.Image
+    import torch
+    from streamingt2v_amd.enhance_codec import center_crop_wide, frame_position_planes
+    lat = torch.randn(1, 4, 3, 5)
+    x = frame_position_planes(lat, 5)
+    assert x.shape == (1, 4, 5, 3, 5) and torch.equal(x[:, :, 0], lat)
+    ref = []
+    for frame_idx in range(4):                                   # the reference's loop
+        ref.append(torch.ones_like(lat.unsqueeze(2)) * ((frame_idx + 1) / 4))
+    assert torch.equal(x[:, :, 1:], torch.cat(ref, 2))
+    assert frame_position_planes(lat, 1).shape == (1, 4, 1, 3, 5)
+    img = PIL.Image.fromarray((np.random.rand(576, 1024, 3) * 255).astype("uint8"))
+    assert center_crop_wide(img, (1280, 720)).size == (1280, 720) and center_crop_wide(img, (1280, 1280)).size == (1280, 1280)

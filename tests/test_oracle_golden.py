@@ -160,3 +160,23 @@ def test_decoder_2d_oracle_matches_reference(golden_dir):
     out = O.vae_decoder_2d(sd, O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), cases.tiny_vae_inputs()["z"][:2])
     gold = torch.load(os.path.join(golden_dir, "vae_dec2d_tiny.pt"))["out"]
     assert out.shape == gold.shape and (out - gold).abs().max().item() <= TOL
+
+
+def test_clip_text_oracle_matches_hf():
+    """oracle/clip_text_oracle.py vs the real transformers.CLIPTextModel (the class the reference's enhancer instantiates)."""
+    pytest = __import__("pytest")
+    tr = pytest.importorskip("transformers")
+    from oracle.clip_text_oracle import text_tower
+    torch.manual_seed(0)
+    cfg = tr.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                            max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5, eos_token_id=2, bos_token_id=0, pad_token_id=1)
+    hf = tr.CLIPTextModel(cfg).eval()
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.normal_(0, 0.05)
+        ids = torch.randint(3, 1000, (2, 77))
+        ref = hf(input_ids=ids).last_hidden_state
+        # transformers 4.40 (the reference's pin, and the published checkpoint) prefixes the keys with "text_model."; 5.x does not
+        sd = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in hf.state_dict().items() if "position_ids" not in k}
+        out = text_tower(sd, ids, 2)
+    assert (ref - out).abs().max().item() <= 2e-5
