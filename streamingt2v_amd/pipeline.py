@@ -61,6 +61,53 @@ def load_conditioner(state_dict, device="cuda", clip_cfg=None, vae_cfg=None, num
     return SVDConditioner(clip, enc, num_frames=num_frames, generator=generator)
 
 
+def load_enhancer(folder, device="cuda", variant="fp16", generator=None):
+    """The enhancement stage from a diffusers-format ``ali-vilab/i2vgen-xl`` folder (i2v_enhance_interface.py:63-80 loads it with
+    I2VGenXLPipeline.from_pretrained(..., torch_dtype=float16, variant="fp16")): unet/, vae/, text_encoder/, image_encoder/ with their
+    config.json -> (I2VGenXLUNet, EnhanceCodec).  Weights are read from ``*.safetensors`` (``.<variant>`` tried first)."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from .clip_text import CLIPTextTower, ClipTextConfig
+    from .clip_vision import ClipVisionConfig, OpenCLIPVisionTower, hf_clip_vision_to_openclip_keys
+    from .enhance_codec import EnhanceCodec
+    from .i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from .temporal_ae import AutoencoderKL2D, VaeConfig
+
+    def part(name, stem):
+        d = os.path.join(folder, name)
+        cfg = json.load(open(os.path.join(d, "config.json")))
+        for fn in (f"{stem}.{variant}.safetensors", f"{stem}.safetensors"):
+            if os.path.exists(os.path.join(d, fn)):
+                return cfg, load_file(os.path.join(d, fn))
+        raise FileNotFoundError(f"no {stem}[.{variant}].safetensors under {d}")
+
+    ucfg, usd = part("unet", "diffusion_pytorch_model")
+    attn = tuple(t.startswith("CrossAttn") for t in ucfg.get("down_block_types", ("CrossAttnDownBlock3D",) * 3 + ("DownBlock3D",)))
+    unet = I2VGenXLUNet(I2VConfig(block_out_channels=tuple(ucfg.get("block_out_channels", (320, 640, 1280, 1280))),
+                                  layers_per_block=ucfg.get("layers_per_block", 2), cross_attention_dim=ucfg.get("cross_attention_dim", 1024),
+                                  attn_levels=attn)).load_state_dict(usd, device=device)
+    vcfg, vsd = part("vae", "diffusion_pytorch_model")
+    boc = vcfg.get("block_out_channels", (128, 256, 512, 512))
+    vae = AutoencoderKL2D(VaeConfig(boc[0], tuple(c // boc[0] for c in boc), vcfg.get("layers_per_block", 2)),
+                          scaling_factor=vcfg.get("scaling_factor", 0.18215)).load_state_dict(vsd, device=device, diffusers_keys=True)
+    icfg, isd = part("image_encoder", "model")
+    iv = ClipVisionConfig(width=icfg["hidden_size"], layers=icfg["num_hidden_layers"], heads=icfg["num_attention_heads"],
+                          patch_size=icfg["patch_size"], image_size=icfg["image_size"], embed_dim=icfg["projection_dim"],
+                          mlp_ratio=icfg["intermediate_size"] / icfg["hidden_size"])
+    tower = OpenCLIPVisionTower(iv).load_state_dict(hf_clip_vision_to_openclip_keys(isd, iv.layers), device=device)
+    tcfg, tsd = part("text_encoder", "model")
+    tc = ClipTextConfig(vocab_size=tcfg["vocab_size"], hidden_size=tcfg["hidden_size"], intermediate_size=tcfg["intermediate_size"],
+                        num_hidden_layers=tcfg["num_hidden_layers"], num_attention_heads=tcfg["num_attention_heads"],
+                        max_position_embeddings=tcfg["max_position_embeddings"])
+    tsd = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in tsd.items()}
+    text = CLIPTextTower(tc).load_state_dict(tsd, device=device)
+    gen = generator
+    if gen is None and str(device).startswith("cuda"):
+        gen = torch.Generator(device=device).manual_seed(DEFAULTS["enhance_generator_seed"])       # torch.manual_seed(8888), interface :64
+    return unet, EnhanceCodec(vae, tower, text, generator=gen, device=device)
+
+
 def num_autoregressive_generations(num_frames, frames_per_chunk=25, num_conditional_frames=7):
     """inference_i2v.py:182-186."""
     return max(0, math.ceil((num_frames - frames_per_chunk) / (frames_per_chunk - num_conditional_frames)))

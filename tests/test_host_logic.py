@@ -316,3 +316,56 @@ def test_enhance_codec_host_helpers():
     assert frame_position_planes(lat, 1).shape == (1, 4, 1, 3, 5)
     img = PIL.Image.fromarray((np.random.rand(576, 1024, 3) * 255).astype("uint8"))
     assert center_crop_wide(img, (1280, 720)).size == (1280, 720) and center_crop_wide(img, (1280, 1280)).size == (1280, 1280)
+
+
+def test_load_enhancer_from_diffusers_folder(tmp_path):
+    """pipeline.load_enhancer reads a diffusers-format i2vgen-xl folder (config.json + safetensors per component, HF / diffusers key
+    names) into the native UNet + codec; exercised with tiny random components written in that format."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.clip_text import CLIPTextTower, ClipTextConfig
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import AutoencoderKL2D, VaeConfig
+
+    def write(name, stem, cfg, sd):
+        d = tmp_path / name
+        d.mkdir()
+        json.dump(cfg, open(d / "config.json", "w"))
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(d / f"{stem}.fp16.safetensors"))
+
+    ucfg = dict(block_out_channels=[64, 128], layers_per_block=1, cross_attention_dim=128, down_block_types=["CrossAttnDownBlock3D", "DownBlock3D"])
+    write("unet", "diffusion_pytorch_model", ucfg, init_by_name(I2VGenXLUNet(I2VConfig(block_out_channels=(64, 128), layers_per_block=1,
+          cross_attention_dim=128, attn_levels=(True, False))).spec(), seed=1))
+    # VAE written with DIFFUSERS key names (inverse of the map, as in test_diffusers_vae_key_map_roundtrip)
+    sgm = init_by_name(AutoencoderKL2D(VaeConfig(32, (1, 2), 1)).spec(), seed=2)
+    dif = {}
+    for k, v in sgm.items():
+        part, _, r = k.partition(".")
+        if part in ("quant_conv", "post_quant_conv"):
+            dif[k] = v; continue
+        r = r.replace("norm_out.", "conv_norm_out.").replace("nin_shortcut.", "conv_shortcut.").replace("mid.block_1.", "mid_block.resnets.0.").replace("mid.block_2.", "mid_block.resnets.1.")
+        if r.startswith("mid.attn_1."):
+            r = r.replace("mid.attn_1.", "mid_block.attentions.0.").replace("proj_out.", "to_out.0.").replace("norm.", "group_norm.")
+            for n in "qkv":
+                r = r.replace(f"attentions.0.{n}.", f"attentions.0.to_{n}.")
+            v = v[:, :, 0, 0] if v.dim() == 4 else v
+        if r.startswith("down."):
+            _, i, kind, rest = r.split(".", 3)
+            r = f"down_blocks.{i}.resnets.{rest}" if kind == "block" else f"down_blocks.{i}.downsamplers.0.{rest}"
+        if r.startswith("up."):
+            _, lvl, kind, rest = r.split(".", 3)
+            r = f"up_blocks.{1 - int(lvl)}.resnets.{rest}" if kind == "block" else f"up_blocks.{1 - int(lvl)}.upsamplers.0.{rest}"
+        dif[part + "." + r] = v
+    write("vae", "diffusion_pytorch_model", dict(block_out_channels=[32, 64], layers_per_block=1, scaling_factor=0.18215), dif)
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    icfg = dict(hidden_size=320, intermediate_size=1280, num_hidden_layers=1, num_attention_heads=4, image_size=56, patch_size=14, projection_dim=128)
+    hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_act="gelu", **icfg))
+    write("image_encoder", "model", icfg, {k: v for k, v in hf.state_dict().items() if "position_ids" not in k})
+    tcfg = dict(vocab_size=500, hidden_size=128, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2, max_position_embeddings=77)
+    write("text_encoder", "model", tcfg, init_by_name(CLIPTextTower(ClipTextConfig(**tcfg)).spec(), seed=3))
+    unet, codec = P.load_enhancer(str(tmp_path), device="cpu")
+    assert unet.cfg.block_out_channels == (64, 128) and codec.vae.sf == 0.18215 and codec.text_tower.cfg.layers == 1
+    assert codec.image_tower.cfg.embed_dim == 128
