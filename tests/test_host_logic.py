@@ -360,6 +360,7 @@ def test_load_enhancer_from_diffusers_folder(tmp_path):
             r = f"up_blocks.{1 - int(lvl)}.resnets.{rest}" if kind == "block" else f"up_blocks.{1 - int(lvl)}.upsamplers.0.{rest}"
         dif[part + "." + r] = v
     write("vae", "diffusion_pytorch_model", dict(block_out_channels=[32, 64], layers_per_block=1, scaling_factor=0.18215), dif)
+    __import__("pytest").importorskip("transformers")
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
     icfg = dict(hidden_size=320, intermediate_size=1280, num_hidden_layers=1, num_attention_heads=4, image_size=56, patch_size=14, projection_dim=128)
     hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_act="gelu", **icfg))
