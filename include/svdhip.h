@@ -231,6 +231,47 @@ int svd_frames_to_uint8(const float* X, uint8_t* Y, int32_t frames, int32_t pix,
  * models/svd/sgm/modules/encoders/modules.py:574-732 -> open_clip transformer.py ResidualAttentionBlock.mlp). */
 int svd_gelu_rows(svd_bf16* X, int64_t ldx, int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream);
 
+/* ---- EMA-VFI frame interpolation (code/i2v_enhance/thirdparty/VFI, called from inference_i2v.py:211-224 through
+ *      i2v_enhance_interface.vfi_process :30-61).  Convolutions, linears and LayerNorms of the model run on svd_gemm / svd_layernorm;
+ *      the entries below are the remaining operators.  "rows" tensors are channels-last 16-bit [pixels][ld]. ---- */
+
+/* nn.PReLU(channels) in place (model/refine.py:8-19, model/flow_estimation.py:9-14, model/feature_extractor.py:293-305); dtype: a 16-bit
+ * element type (channels % 8 == 0) or SVD_DTYPE_F32. */
+int svd_prelu_rows(void* X, int64_t ldx, int64_t rows, int32_t channels, const float* slope, int32_t dtype, svd_stream_t stream);
+
+/* Mlp.dwconv + act: depthwise 3x3 (padding 1, bias) followed by exact GELU (model/feature_extractor.py:104-108, 505-515).
+ * w9: [9][channels] fp32 (tap-major: w9[(ky*3+kx)*channels + c] = weight[c][0][ky][kx]). */
+int svd_dwconv3x3_gelu(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, const float* w9, const float* bias, int32_t frames,
+                       int32_t h, int32_t w, int32_t channels, int32_t dtype, svd_stream_t stream);
+
+/* InterFrameAttention.forward on 7x7 windows, head dim 32 (model/feature_extractor.py:141-171).  Q [n_win*49][ldq], KV [n_win*49][ldkv]
+ * (k | v, each heads*32 wide), CE [n_win*49][ldce] fp32 = cor_embed (heads * motion_per_head wide, motion_per_head <= 16).  Window w
+ * attends to the keys/values of window (w + n_win/2) % n_win (the other frame, :264).  mask: [n_mask][49][49] fp32 or NULL; window w
+ * uses mask[w % n_mask].  OX = softmax(q k^T scale + mask) v;  OC = softmax(..) ce - ce  (c_reverse - cor_embed_, :166-168). */
+int svd_window_attn_7x7(const svd_bf16* Q, int64_t ldq, const svd_bf16* KV, int64_t ldkv, const float* CE, int64_t ldce, const float* mask,
+                        int32_t n_mask, svd_bf16* OX, int64_t ldo, svd_bf16* OC, int64_t ldc, int32_t n_win, int32_t heads,
+                        int32_t motion_per_head, float scale, int32_t dtype, svd_stream_t stream);
+
+/* warp(tenInput, tenFlow) (model/warplayer.py:7-22): grid_sample(bilinear, border, align_corners=True) at (x + flow[0], y + flow[1]).
+ * X/Y channels-last [frames*h*w][ld]; dtype SVD_DTYPE_F32 (any channel count) or a 16-bit type (channels % 8 == 0);
+ * flow: fp32, two values per pixel at flow[pixel * ldf]. */
+int svd_warp_bilinear(const void* X, int64_t ldx, void* Y, int64_t ldy, const float* flow, int64_t ldf, int32_t frames, int32_t h, int32_t w,
+                      int32_t channels, int32_t dtype, svd_stream_t stream);
+
+/* F.interpolate(scale_factor, mode="bilinear", align_corners=False) on channels-last fp32 (model/flow_estimation.py:30-39,64):
+ * Y[c] = (accumulate ? Y[c] : 0) + mult[c] * interp(X)[c]  (mult NULL = 1); hout/wout = floor(in * scale_factor) is the caller's. */
+int svd_resize_bilinear_f32(const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t frames, int32_t hin, int32_t win, int32_t hout,
+                            int32_t wout, int32_t channels, float scale_factor, const float* mult, int32_t accumulate, svd_stream_t stream);
+
+/* merged = w0 sigmoid(mask) + w1 (1 - sigmoid(mask)); pred = clamp(merged + sigmoid(unet_out[:3]) * 2 - 1, 0, 1)
+ * (model/flow_estimation.py:131-139, model/refine.py:71).  warped0/1, merged (may be NULL), pred: fp32 [n_pixels][3]. */
+int svd_vfi_merge(const float* warped0, const float* warped1, const float* mask, int64_t ld_mask, const float* unet_out, int64_t ld_unet,
+                  float* merged, float* pred, int64_t n_pixels, svd_stream_t stream);
+
+/* fast-TTA average (Trainer.py:90-94): out = (pred2[0] + rot180(pred2[1])) / 2 on [2][h][w][3] fp32; out_u8 (optional) =
+ * (uint8)(out * 255.0f), the truncation of i2v_enhance_interface.py:46-47. */
+int svd_vfi_tta_average(const float* pred2, float* out, uint8_t* out_u8, int32_t h, int32_t w, svd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,3 +111,26 @@ def range_inputs():
     vals = torch.cat(vals).clamp(-1, 1)
     flat[: vals.numel()] = vals
     return x
+
+
+# ---- EMA-VFI (code/i2v_enhance/thirdparty/VFI): tiny configuration F=8 (production F=32), same depths / window / head dim ----
+TINY_VFI = dict(F=8, depth=(2, 2, 2, 4, 4), H=48, W=80)
+
+
+def vfi_weights(spec, seed=11):
+    """init_by_name, except PReLU slopes (1-D ``.weight`` of a non-norm layer) ~ 0.25 + 0.1 N so that the negative branch matters."""
+    from streamingt2v_amd.params import init_by_name
+    sd = init_by_name(spec, seed=seed)
+    for name, shape in spec:
+        if len(shape) == 1 and name.endswith(".weight") and "norm" not in name:
+            sd[name] = 0.25 + 0.1 * (sd[name] - 1.0) / 0.1
+    return sd
+
+
+def tiny_vfi_inputs():
+    """Two smooth-ish frames in [0, 1] (BGR order is irrelevant here): low-resolution noise upsampled, second frame shifted."""
+    g = _gen(2024)
+    H, W = TINY_VFI["H"], TINY_VFI["W"]
+    base = torch.nn.functional.interpolate(torch.rand(1, 3, H // 4 + 2, W // 4 + 2, generator=g), scale_factor=4, mode="bicubic",
+                                           align_corners=False).clamp(0, 1)
+    return dict(img0=base[:, :, 2:2 + H, 3:3 + W].contiguous(), img1=base[:, :, 4:4 + H, 1:1 + W].contiguous())

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""), "libsvdhip.so"))   # probe: developer build with a reduced tile table
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
@@ -20,6 +20,7 @@ SYMBOLS = [
     "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32",
     "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
     "svd_attn_cross_d64", "svd_adaptive_avgpool_tokens", "svd_i2v_image_temporal_encoder", "svd_ddim_cfg_step", "svd_frames_to_uint8", "svd_gelu_rows",
+    "svd_prelu_rows", "svd_dwconv3x3_gelu", "svd_window_attn_7x7", "svd_warp_bilinear", "svd_resize_bilinear_f32", "svd_vfi_merge", "svd_vfi_tta_average",
 ]
 
 A_PLAIN, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
@@ -100,6 +101,13 @@ def _load():
     lib.svd_ddim_cfg_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, i32, vp]
     lib.svd_frames_to_uint8.argtypes = [vp, vp, i32, i32, vp]
     lib.svd_gelu_rows.argtypes = [vp, i64, i64, i32, i32, vp]
+    lib.svd_prelu_rows.argtypes = [vp, i64, i64, i32, vp, i32, vp]
+    lib.svd_dwconv3x3_gelu.argtypes = [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.svd_window_attn_7x7.argtypes = [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, i64, i32, i32, i32, f32, i32, vp]
+    lib.svd_warp_bilinear.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]
+    lib.svd_resize_bilinear_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp]
+    lib.svd_vfi_merge.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, i64, vp]
+    lib.svd_vfi_tta_average.argtypes = [vp, vp, vp, i32, i32, vp]
     for s in SYMBOLS:
         fn = getattr(lib, s)
         if s not in ("svd_last_error", "svd_groupnorm_partial_elems"):

@@ -348,3 +348,85 @@ def gelu_(x):
     rows, ld = _rows_ld(x)
     check(_lib.svd_gelu_rows(_p(x), ld, rows, x.shape[1], _dt(x), _stream()), "svd_gelu_rows")
     return x
+
+
+# ---- EMA-VFI operators (csrc/vfi.hip) ---------------------------------------------------------------------------------------------
+def prelu_(x, slope):
+    """nn.PReLU in place on a [rows, C] 16-bit token tensor; slope fp32 [C]."""
+    rows, ld = _rows_ld(x)
+    assert slope.dtype == torch.float32 and slope.numel() >= x.shape[1]
+    check(_lib.svd_prelu_rows(_p(x), ld, rows, x.shape[1], _p(slope), _dt(x), _stream()), "svd_prelu_rows")
+    return x
+
+
+def dwconv3x3_gelu(x, w9, bias, frames, h, w):
+    """depthwise 3x3 (padding 1) + bias + exact GELU on [frames*h*w, C] tokens; w9 fp32 [9, C]."""
+    rows, ld = _rows_ld(x)
+    assert rows == frames * h * w and w9.dtype == torch.float32 and bias.dtype == torch.float32
+    out = torch.empty((rows, x.shape[1]), dtype=x.dtype, device=x.device)
+    check(_lib.svd_dwconv3x3_gelu(_p(x), ld, _p(out), out.stride(0), _p(w9), _p(bias), frames, h, w, x.shape[1], _dt(x), _stream()),
+          "svd_dwconv3x3_gelu")
+    return out
+
+
+def window_attn_7x7(q, kv, ce, mask, n_win, heads, motion_per_head, scale):
+    """q [n_win*49, >=heads*32], kv [n_win*49, >=2*heads*32] 16-bit; ce fp32 [n_win*49, >=heads*mph]; mask fp32 [nW, 49, 49] or None.
+    Returns (x [n_win*49, heads*32], c_reverse - cor_embed [n_win*49, heads*mph]) in the element type."""
+    assert q.shape[0] == n_win * 49 and kv.shape[0] == n_win * 49 and ce.shape[0] == n_win * 49 and ce.dtype == torch.float32
+    ox = torch.empty((n_win * 49, heads * 32), dtype=q.dtype, device=q.device)
+    oc = torch.empty((n_win * 49, heads * motion_per_head), dtype=q.dtype, device=q.device)
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.is_contiguous() and tuple(mask.shape[1:]) == (49, 49)
+    check(_lib.svd_window_attn_7x7(_p(q), q.stride(0), _p(kv), kv.stride(0), _p(ce), ce.stride(0), _p(mask), mask.shape[0] if mask is not None else 0,
+                                   _p(ox), ox.stride(0), _p(oc), oc.stride(0), n_win, heads, motion_per_head, float(scale), _dt(q), _stream()),
+          "svd_window_attn_7x7")
+    return ox, oc
+
+
+def warp_bilinear(x, flow, frames, h, w):
+    """backward warp of channels-last x [frames*h*w, C] (fp32 or 16-bit) by flow: fp32 view [frames*h*w, 2] (row stride arbitrary)."""
+    rows, ld = _rows_ld(x)
+    assert rows == frames * h * w and flow.dtype == torch.float32 and flow.shape == (rows, 2) and flow.stride(1) == 1
+    out = torch.empty((rows, x.shape[1]), dtype=x.dtype, device=x.device)
+    check(_lib.svd_warp_bilinear(_p(x), ld, _p(out), out.stride(0), _p(flow), flow.stride(0), frames, h, w, x.shape[1], _dt(x), _stream()),
+          "svd_warp_bilinear")
+    return out
+
+
+def resize_bilinear(x, frames, hin, win, scale_factor, *, mult=None, out=None, accumulate=False):
+    """F.interpolate(bilinear, align_corners=False, scale_factor) on channels-last fp32 x [frames*hin*win, C] -> ([frames*hout*wout, C], hout, wout);
+    out (+)= mult[c] * value."""
+    rows, ld = _rows_ld(x)
+    assert x.dtype == torch.float32 and rows == frames * hin * win
+    hout, wout = int(hin * scale_factor), int(win * scale_factor)
+    Cc = x.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((frames * hout * wout, Cc), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.shape[0] == frames * hout * wout and out.stride(1) == 1 and out.shape[1] >= Cc
+    if mult is not None:
+        assert mult.dtype == torch.float32 and mult.numel() >= Cc
+    check(_lib.svd_resize_bilinear_f32(_p(x), ld, _p(out), out.stride(0), frames, hin, win, hout, wout, Cc, float(scale_factor), _p(mult),
+                                       int(accumulate), _stream()), "svd_resize_bilinear_f32")
+    return out, hout, wout
+
+
+def vfi_merge(warped0, warped1, mask, unet_out, want_merged=False):
+    """fp32 [n, 3] x2, mask view [n, 1], unet_out [n, >=3] (pre-sigmoid) -> pred [n, 3] (and merged)."""
+    n = warped0.shape[0]
+    assert all(t.dtype == torch.float32 for t in (warped0, warped1, mask, unet_out)) and warped0.is_contiguous() and warped1.is_contiguous()
+    assert mask.shape[0] == n and unet_out.shape[0] == n and unet_out.stride(1) == 1
+    pred = torch.empty((n, 3), dtype=torch.float32, device=warped0.device)
+    merged = torch.empty_like(pred) if want_merged else None
+    check(_lib.svd_vfi_merge(_p(warped0), _p(warped1), _p(mask), mask.stride(0), _p(unet_out), unet_out.stride(0), _p(merged), _p(pred), n,
+                             _stream()), "svd_vfi_merge")
+    return (pred, merged) if want_merged else pred
+
+
+def vfi_tta_average(pred2, h, w, want_uint8=False):
+    """pred2 fp32 [2*h*w, 3] (the pair and its 180-degree rotation) -> (average fp32 [h*w, 3], uint8 [h, w, 3] or None)."""
+    assert pred2.dtype == torch.float32 and pred2.is_contiguous() and pred2.shape == (2 * h * w, 3)
+    out = torch.empty((h * w, 3), dtype=torch.float32, device=pred2.device)
+    u8 = torch.empty((h, w, 3), dtype=torch.uint8, device=pred2.device) if want_uint8 else None
+    check(_lib.svd_vfi_tta_average(_p(pred2), _p(out), _p(u8), h, w, _stream()), "svd_vfi_tta_average")
+    return out, u8

@@ -1,0 +1,92 @@
+"""EMA-VFI on CPU: the oracle against the golden vectors of the vendored network, and the HOST logic of
+streamingt2v_amd.ema_vfi (layout, padding, window partition / shift, weight packing, transposed-conv and im2col rewrites, channel
+bookkeeping) with the HIP launchers replaced by the fp32 torch statements of tests/vfi_shim.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import vfi_oracle as O  # noqa: E402
+from oracle.cases import TINY_VFI, tiny_vfi_inputs, vfi_weights  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden", "vfi_tiny.pt")
+
+
+def _tiny():
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    model = EMAVFI(VFIConfig(F=TINY_VFI["F"], depth=TINY_VFI["depth"]))
+    sd = vfi_weights(model.spec())
+    inp = tiny_vfi_inputs()
+    imgs = torch.cat((inp["img0"], inp["img1"]), 1)
+    return model, sd, inp, torch.cat((imgs, imgs.flip(2).flip(3)), 0)
+
+
+def test_vfi_oracle_matches_vendored_golden():
+    torch.set_grad_enabled(False)
+    _, sd, inp, x = _tiny()
+    g = torch.load(GOLD)
+    cfg = O.vfi_config(TINY_VFI["F"], TINY_VFI["depth"])
+    o = O.net_forward(sd, cfg, x)
+    assert (o["flow"] - g["flow"]).abs().max() <= 1e-4
+    for k, v in (("af4", o["af"][4]), ("mf4", o["mf"][1]), ("mask", torch.sigmoid(o["mask"])), ("merged", o["merged"]), ("pred", o["pred"])):
+        assert (v - g[k].float()).abs().max() <= 2e-3, k                     # stored as fp16
+    assert (O.inference_fast_tta(sd, cfg, inp["img0"], inp["img1"]) - g["tta"]).abs().max() <= 1e-4
+
+
+def test_vfi_host_logic_matches_oracle(monkeypatch):
+    import vfi_shim
+    torch.set_grad_enabled(False)
+    vfi_shim.install(monkeypatch)
+    model, sd, inp, x = _tiny()
+    model.load_state_dict(sd, device="cpu")
+    H, W = TINY_VFI["H"], TINY_VFI["W"]
+    cl = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()                  # NCHW -> channels-last rows
+    r = model.net_forward(cl(x[:, :3]), cl(x[:, 3:6]), 2, H, W, want=True)
+    o = O.net_forward(sd, O.vfi_config(TINY_VFI["F"], TINY_VFI["depth"]), x)
+    for lvl in range(5):
+        t, C, h, w = r["af"][lvl]
+        assert (t[:, :C] - cl(o["af"][lvl])).abs().max() <= 2e-4, f"af{lvl}"
+    for k in range(2):
+        t, C, h, w = r["mf"][k]
+        assert (t[:, :C] - cl(o["mf"][k])).abs().max() <= 2e-4, f"mf{k + 3}"
+    assert (r["fm"][:, :4] - cl(o["flow"])).abs().max() <= 5e-4
+    assert (r["fm"][:, 4:5] - cl(o["mask"])).abs().max() <= 5e-4
+    assert (r["merged"] - cl(o["merged"])).abs().max() <= 2e-4
+    assert (r["pred"] - cl(o["pred"])).abs().max() <= 2e-4
+    mid = model.inference(inp["img0"][0].permute(1, 2, 0).contiguous(), inp["img1"][0].permute(1, 2, 0).contiguous())
+    g = torch.load(GOLD)
+    assert (mid - g["tta"][0].permute(1, 2, 0)).abs().max() <= 2e-4                            # against the VENDORED network's fast-TTA output
+
+
+def test_vfi_process_frame_arithmetic(monkeypatch):
+    """i2v_enhance_interface.vfi_process :30-61: frame selection / interleaving / duplication, BGR flip, uint8 truncation, 1280x720 resize."""
+    from streamingt2v_amd import ema_vfi
+
+    class Fake:
+        def inference(self, a, b, want_uint8=False):
+            m = (a + b) / 2
+            return m, (m * 255.0).to(torch.uint8)
+
+    rng = np.random.default_rng(0)
+    video = [rng.integers(0, 256, (16, 32, 3), dtype=np.uint8) for _ in range(6)]
+    infer = lambda a, b: (a + b) / 2
+    for n, have in ((7, 4), (8, 4), (5, 3), (8, 6)):        # the pipeline hands over (n + 1) // 2 frames; surplus frames follow the reference too
+        got = ema_vfi.vfi_process(video[:have], Fake(), n, out_size=(64, 32), device="cpu")
+        ref = O.vfi_process(video[:have], infer, n, out_size=(64, 32))
+        assert len(got) == len(ref) and (have != (n + 1) // 2 or len(got) == n)
+        for a, b in zip(got, ref):
+            assert a.size == (64, 32) and np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_window_geometry_matches_oracle():
+    from streamingt2v_amd.ema_vfi import window_geometry
+    for h, w in ((6, 10), (3, 5), (7, 14), (90, 160)):
+        for shift in (0, 3):
+            a, b = window_geometry(h, w, 7, shift), O.window_masks(h, w, 7, shift)
+            assert a[:2] == b[:2]
+            assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2]))
