@@ -10,7 +10,7 @@ What is native here: the checkpoint key map (same `state_dict` keys, strict), ch
 enhancement loop with randomized blending and its key-frame pre-pass, range conversions.  What is an injected callable
 (not on the measured path): the conditioners -- OpenCLIP image tower + VAE encoder for stage 1
 (``conditioner(frame[3,H,W] in [-1,1]) -> (c, uc)``), CLIP text/vision + AutoencoderKL encode/decode for the enhancer
-(``enhance_codec``), and EMA-VFI (``vfi``).  Calling a stage whose callable was not supplied raises NotImplementedError that names it.
+(``enhance_codec``), and ``vfi`` (`ema_vfi.EMAVFI`, the native EMA-VFI, or any callable).  Calling a stage whose callable was not supplied raises NotImplementedError that names it.
 """
 import math
 import random
@@ -192,9 +192,15 @@ class StreamingPipeline:
         return codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng))
 
     def interpolate_video(self, video, dest_num_frames, **kwargs):
+        """inference_i2v.py:211-224.  vfi: an `ema_vfi.EMAVFI` (the native EMA-VFI) or any callable vfi(video, dest_num_frames)."""
         if self.vfi is None:
-            raise NotImplementedError("interpolate_video needs vfi(video, dest_num_frames): EMA-VFI (code/i2v_enhance/thirdparty/VFI) "
-                                      "is outside the MI355X path (SURVEY.md 8f N4)")
+            raise NotImplementedError("interpolate_video needs vfi: ema_vfi.EMAVFI().load_state_dict(EMAVFI.convert_checkpoint(torch.load('ours.pkl'))) "
+                                      "(code/i2v_enhance/thirdparty/VFI, SURVEY.md 8f N4) or a callable vfi(video, dest_num_frames)")
+        from .ema_vfi import EMAVFI, vfi_process
+        if isinstance(self.vfi, EMAVFI):
+            import numpy as np
+            frames = vfi_process(list(video), self.vfi, dest_num_frames, device=self.vfi.device)
+            return np.stack([np.asarray(f) for f in frames], axis=0)
         return self.vfi(video, dest_num_frames)
 
     def __call__(self, image):
