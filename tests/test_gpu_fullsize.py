@@ -141,3 +141,31 @@ def test_full_size_vae_decode_deterministic():
     assert a.shape == (8, 3, 576, 1024) and torch.isfinite(a).all()
     assert torch.equal(a, b), "decode is not deterministic"
     assert not torch.equal(a[7], c[7]) and not torch.equal(a[0], c[0])
+
+
+def test_full_size_vfi_rotation_equivariance_and_determinism():
+    """EMA-VFI at the shipped size (F = 32, 720x1280, 65.7 M parameters), where the CPU oracle needs ~a minute per pair: fast TTA averages
+    the prediction of the pair with the back-rotated prediction of the 180-degree rotated pair (Trainer.py:90-94), so interpolating the
+    rotated frames must give EXACTLY the rotated middle frame (the two batch rows swap roles; fp32 addition commutes) -- this holds only if
+    every kernel treats batch rows independently and deterministically.  Also: two runs are bit-identical, the uint8 frame is the
+    truncation of the fp32 one, and the result stays inside [0, 1]."""
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    from streamingt2v_amd.params import init_by_name
+    ops.set_element_dtype(torch.bfloat16)
+    torch.set_grad_enabled(False)
+    m = EMAVFI(VFIConfig())
+    m.load_state_dict(init_by_name(m.spec(), seed=3), device="cuda")
+    g = torch.Generator().manual_seed(5)
+    low = torch.rand(2, 3, 45, 80, generator=g)
+    f0, f1 = (torch.nn.functional.interpolate(low[i:i + 1], size=(720, 1280), mode="bicubic").clamp(0, 1)[0].permute(1, 2, 0).contiguous().cuda()
+              for i in range(2))
+    a, a8 = m.inference(f0, f1, want_uint8=True)
+    b, b8 = m.inference(f0, f1, want_uint8=True)
+    assert torch.equal(a, b) and torch.equal(a8, b8), "EMA-VFI is not deterministic"
+    rot = lambda t: t.flip(0).flip(1).contiguous()
+    r, _ = m.inference(rot(f0), rot(f1), want_uint8=True)
+    assert torch.equal(rot(r), a), f"rotation equivariance broken: max diff {(rot(r) - a).abs().max().item():.3e}"
+    assert torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+    assert torch.equal(a8, (a * 255.0).to(torch.uint8))
+    print(f"[vfi full size] mean {a.mean().item():.4f}, |mid - (f0+f1)/2| mean {(a - (f0 + f1) / 2).abs().mean().item():.4f}")
