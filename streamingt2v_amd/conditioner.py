@@ -6,8 +6,10 @@ StreamingSVD._generate_conditional_output (code/diffusion_trainer/streaming_svd.
     vector    [T, 768]      sinusoidal embeddings (256 each) of fps_id 6, motion_bucket_id 127, cond_aug 0.02, in that order
     uc        crossattn and concat zeroed (force_uc_zero_embeddings), vector unchanged
 
-The only piece that is not the reference's arithmetic: the 224 x 224 CLIP resize.  The reference uses kornia's antialiased bicubic
-resize (modules.py:624-636; kornia is not vendored); here it is torch's antialiased bicubic interpolate -- close, not identical.
+The 224 x 224 CLIP resize is kornia's ``geometry.resize(..., "bicubic", align_corners=True, antialias=True)`` (modules.py:624-636).
+kornia==0.7.2 is neither vendored nor installed: `kornia_resize_antialias` restates its published algorithm (Gaussian blur with
+sigma = (factor - 1) / 2 per axis, kernel size 4 sigma made odd, reflect border, separable; then F.interpolate bicubic) -- host-side image
+preprocessing of ONE frame per chunk, **parity unpinned** against kornia itself.
 """
 import math
 
@@ -25,6 +27,33 @@ def sinusoid(values, dim=256, max_period=10000.0):
     return torch.cat([torch.cos(args), torch.sin(args)], -1)
 
 
+def _gaussian_kernel1d(ks, sigma, device):
+    x = torch.arange(ks, device=device, dtype=torch.float32) - ks // 2
+    if ks % 2 == 0:
+        x = x + 0.5
+    g = torch.exp(-x.pow(2.0) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def kornia_resize_antialias(x, size, interpolation="bicubic", align_corners=True):
+    """kornia.geometry.transform.resize(x, size, interpolation, align_corners, antialias=True) of kornia 0.7.2 (affwarp.py): blur only when
+    downscaling; sigmas = max((factor - 1) / 2, 0.001); kernel = int(max(4 sigma, 3)) made odd; gaussian_blur2d(border 'reflect', separable)."""
+    h, w = x.shape[-2:]
+    if (h, w) == tuple(size):
+        return x
+    factors = (h / size[0], w / size[1])
+    if max(factors) > 1:
+        sig = (max((factors[0] - 1.0) / 2.0, 0.001), max((factors[1] - 1.0) / 2.0, 0.001))
+        ks = [int(max(2.0 * 2 * s, 3)) for s in sig]
+        ks = [k + 1 if k % 2 == 0 else k for k in ks]
+        C = x.shape[1]
+        ky, kx = _gaussian_kernel1d(ks[0], sig[0], x.device), _gaussian_kernel1d(ks[1], sig[1], x.device)
+        xp = F.pad(x, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode="reflect")
+        xp = F.conv2d(xp, kx.view(1, 1, 1, -1).expand(C, 1, 1, -1), groups=C)             # filter2d_separable: x pass, then y pass
+        x = F.conv2d(xp, ky.view(1, 1, -1, 1).expand(C, 1, -1, 1), groups=C)
+    return F.interpolate(x, size=tuple(size), mode=interpolation, align_corners=align_corners)
+
+
 class SVDConditioner:
     def __init__(self, clip_tower, cond_encoder, num_frames=25, fps_id=6, motion_bucket_id=127, cond_aug=0.02, generator=None):
         self.clip, self.enc, self.T = clip_tower, cond_encoder, num_frames
@@ -33,7 +62,7 @@ class SVDConditioner:
     @staticmethod
     def clip_preprocess(img):
         """[n, 3, H, W] in [-1, 1] -> CLIP-normalised [n, 3, 224, 224] (modules.py:624-636)."""
-        x = F.interpolate(img.float(), size=(224, 224), mode="bicubic", align_corners=True, antialias=True)
+        x = kornia_resize_antialias(img.float(), (224, 224), "bicubic", align_corners=True)
         x = (x + 1.0) / 2.0
         mean = torch.tensor(CLIP_MEAN, device=x.device).view(1, 3, 1, 1)
         std = torch.tensor(CLIP_STD, device=x.device).view(1, 3, 1, 1)

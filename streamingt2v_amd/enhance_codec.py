@@ -11,8 +11,8 @@ consumes:
     decode(latents)                 decode_latents :384-406          one frame at a time, (x / 2 + 0.5).clamp(0, 1) -> uint8
 
 Host-side image handling follows the reference's own helpers: `_center_crop_wide` (PIL BOX resize + centre crop, :965-1000) and
-`_resize_bilinear` (:952-962) are restated with PIL; normalisation constants are CLIP's.  The tokenizer is not available offline: the
-caller passes token ids (`set_prompts_from_ids`) or ready prompt embeddings.
+`_resize_bilinear` (:952-962) are restated with PIL; normalisation constants are CLIP's.  Prompts go through `clip_tokenizer.CLIPBPETokenizer` (`set_prompts`; the
+vocabulary files come with the checkpoint), or the caller passes token ids (`set_prompts_from_ids`) / ready prompt embeddings.
 """
 import numpy as np
 import torch
@@ -52,6 +52,12 @@ class EnhanceCodec:
         """token ids [1, 77] of the prompt / negative prompt (CLIPTokenizer output, padding='max_length'; encode_prompt :250-347)."""
         self.prompt_embeds = self.text_tower(prompt_ids)
         self.negative_prompt_embeds = self.text_tower(negative_ids)
+
+    def set_prompts(self, prompt, negative_prompt, tokenizer):
+        """prompt strings through `clip_tokenizer.CLIPBPETokenizer` (or any tokenizer with the transformers call signature)."""
+        ids = lambda t: torch.tensor([tokenizer(t, padding="max_length", max_length=tokenizer.model_max_length, truncation=True)["input_ids"]],
+                                     dtype=torch.long, device=self.dev)
+        self.set_prompts_from_ids(ids(prompt), ids(negative_prompt))
 
     def set_prompt_embeds(self, prompt_embeds, negative_prompt_embeds):
         self.prompt_embeds, self.negative_prompt_embeds = prompt_embeds.to(self.dev).float(), negative_prompt_embeds.to(self.dev).float()

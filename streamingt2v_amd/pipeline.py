@@ -105,7 +105,12 @@ def load_enhancer(folder, device="cuda", variant="fp16", generator=None):
     gen = generator
     if gen is None and str(device).startswith("cuda"):
         gen = torch.Generator(device=device).manual_seed(DEFAULTS["enhance_generator_seed"])       # torch.manual_seed(8888), interface :64
-    return unet, EnhanceCodec(vae, tower, text, generator=gen, device=device)
+    codec = EnhanceCodec(vae, tower, text, generator=gen, device=device)
+    tok_dir = os.path.join(folder, "tokenizer")
+    if os.path.exists(os.path.join(tok_dir, "vocab.json")):        # the pipeline's CLIPTokenizer files: prompts of i2v_enhance_interface.py:99-100
+        from .clip_tokenizer import CLIPBPETokenizer
+        codec.set_prompts(DEFAULTS["prompt"], DEFAULTS["negative_prompt"], CLIPBPETokenizer.from_pretrained(tok_dir))
+    return unet, codec
 
 
 def num_autoregressive_generations(num_frames, frames_per_chunk=25, num_conditional_frames=7):

@@ -370,3 +370,91 @@ def test_load_enhancer_from_diffusers_folder(tmp_path):
     unet, codec = P.load_enhancer(str(tmp_path), device="cpu")
     assert unet.cfg.block_out_channels == (64, 128) and codec.vae.sf == 0.18215 and codec.text_tower.cfg.layers == 1
     assert codec.image_tower.cfg.embed_dim == 128
+
+
+def test_clip_tokenizer_matches_transformers_on_synthetic_vocab():
+    """streamingt2v_amd.clip_tokenizer against transformers' CLIPTokenizer (the class the reference loads, pipeline_i2vgen_xl.py:213-231)
+    on a synthetic byte-level BPE vocabulary (no real vocabulary offline): ids, framing, truncation, padding with either pad token."""
+    pytest = __import__("pytest")
+    pytest.importorskip("transformers"); pytest.importorskip("tokenizers")
+    from collections import Counter
+    from transformers import CLIPTokenizer
+    from streamingt2v_amd.clip_tokenizer import CLIPBPETokenizer, bytes_to_unicode
+    from streamingt2v_amd.pipeline import DEFAULTS
+    corpus = (DEFAULTS["prompt"] + " " + DEFAULTS["negative_prompt"] + " a photo of an astronaut riding a horse on mars, it's 4k, don't blur; "
+              "the quick brown fox jumps over the lazy dog 1234567890 times! high-quality detailed details quality").lower().split()
+    be = bytes_to_unicode()
+    words = Counter(tuple(list("".join(be[b] for b in w.encode())[:-1]) + ["".join(be[b] for b in w.encode())[-1] + "</w>"]) for w in corpus)
+    merges = []
+    for _ in range(120):                                               # plain BPE training: most frequent adjacent pair first
+        pairs = Counter()
+        for w, c in words.items():
+            for a, b in zip(w, w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        (a, b), _ = max(sorted(pairs.items()), key=lambda kv: kv[1])
+        merges.append(f"{a} {b}")
+        nw = Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i < len(w) - 1 and w[i] == a and w[i + 1] == b:
+                    out.append(a + b); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            nw[tuple(out)] += c
+        words = nw
+    alphabet = list(be.values())
+    tokens = alphabet + [c + "</w>" for c in alphabet] + [m.replace(" ", "") for m in merges] + ["<|startoftext|>", "<|endoftext|>"]
+    vocab = {t: i for i, t in enumerate(dict.fromkeys(tokens))}
+    texts = [DEFAULTS["prompt"], DEFAULTS["negative_prompt"], "", "  A photo\tof an  astronaut, riding a horse!!  ", "it's don't we'll I'm they've he'd you're",
+             "über café naïve 123 4k ... ?!", "quality " * 100, "<|endoftext|> tail", "emoji \U0001F600 and 中文 text"]
+    for pad in ("<|endoftext|>", "!"):
+        hf = CLIPTokenizer(vocab=vocab, merges=[tuple(m.split()) for m in merges], pad_token=pad, model_max_length=77)
+        ours = CLIPBPETokenizer(vocab, merges, pad_token=pad)
+        for t in texts:
+            ref = hf(t, padding="max_length", max_length=77, truncation=True)
+            got = ours(t)
+            assert got["input_ids"] == ref["input_ids"], (pad, t, got["input_ids"][:20], ref["input_ids"][:20])
+            assert got["attention_mask"] == ref["attention_mask"], (pad, t)
+            assert len(got["input_ids"]) == 77
+    both = ours([texts[0], texts[1]])
+    assert both["input_ids"][1] == ours(texts[1])["input_ids"] and tuple(ours.input_ids(texts[0]).shape) == (1, 77)
+
+
+def test_clip_tokenizer_from_pretrained_folder(tmp_path):
+    import json
+    from streamingt2v_amd.clip_tokenizer import CLIPBPETokenizer, bytes_to_unicode
+    alphabet = list(bytes_to_unicode().values())
+    tokens = alphabet + [c + "</w>" for c in alphabet] + ["hi</w>", "<|startoftext|>", "<|endoftext|>"]
+    (tmp_path / "vocab.json").write_text(json.dumps({t: i for i, t in enumerate(tokens)}), encoding="utf-8")
+    (tmp_path / "merges.txt").write_text("#version: 0.2\nh i</w>\n", encoding="utf-8")
+    (tmp_path / "special_tokens_map.json").write_text(json.dumps({"pad_token": "!", "bos_token": {"content": "<|startoftext|>"}}))
+    (tmp_path / "tokenizer_config.json").write_text(json.dumps({"model_max_length": 16}))
+    tok = CLIPBPETokenizer.from_pretrained(str(tmp_path))
+    out = tok("Hi hi!")
+    v = tok.encoder
+    assert out["input_ids"] == [v["<|startoftext|>"], v["hi</w>"], v["hi</w>"], v["!"], v["<|endoftext|>"]] + [v["!"]] * 11
+    assert out["attention_mask"] == [1] * 5 + [0] * 11
+
+
+def test_kornia_resize_restatement_properties():
+    """conditioner.kornia_resize_antialias (kornia 0.7.2 resize, antialias=True): no-op at equal size, plain interpolate when upscaling,
+    constants preserved, and for 576x1024 -> 224x224 a (3, 7)-tap Gaussian with sigma ((576/224 - 1)/2, (1024/224 - 1)/2) before bicubic."""
+    import torch.nn.functional as F
+    from streamingt2v_amd.conditioner import _gaussian_kernel1d, kornia_resize_antialias
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 36, 64, generator=g)
+    assert kornia_resize_antialias(x, (36, 64)) is x
+    assert torch.equal(kornia_resize_antialias(x, (72, 128)), F.interpolate(x, size=(72, 128), mode="bicubic", align_corners=True))
+    c = torch.full((1, 3, 576, 1024), 0.37)
+    assert (kornia_resize_antialias(c, (224, 224)) - 0.37).abs().max() < 1e-5
+    big = torch.rand(1, 1, 576, 1024, generator=g)
+    sy, sx = (576 / 224 - 1) / 2, (1024 / 224 - 1) / 2
+    assert int(max(4 * sy, 3)) == 3 and int(max(4 * sx, 3)) == 7
+    ky, kx = _gaussian_kernel1d(3, sy, "cpu"), _gaussian_kernel1d(7, sx, "cpu")
+    k2 = ky[:, None] * kx[None, :]
+    ref = F.conv2d(F.pad(big, (3, 3, 1, 1), mode="reflect"), k2[None, None])
+    ref = F.interpolate(ref, size=(224, 224), mode="bicubic", align_corners=True)
+    assert (kornia_resize_antialias(big, (224, 224)) - ref).abs().max() < 1e-5
