@@ -8,9 +8,11 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 M = 460800
 NOL, NOM, NOE = 1 << 30, 1 << 29, 1 << 27
 VAR = [("full", 0), ("no_epi", NOE), ("loads_only", NOM | NOE), ("mfma_only", NOL | NOE), ("epi_only", NOL | NOM), ("loads+epi", NOM), ("mfma+epi", NOL)]
+if os.environ.get("PROBE_FULL_ONLY"):
+    VAR = [("full", 0)]
 if os.environ.get("PROBE_STAGGER"):
     VAR = [("full", 0)] + [(f"stag{s}", s << 20) for s in (4, 8, 16, 24, 32, 48, 63)]
-shapes = [(2560, 320, 1, 0), (320, 320, 0, 1), (1280, 1280, 0, 0), (320, 2880, 0, 0), (1280, 5120, 0, 1)]
+shapes = [(2560, 320, 1, 0), (320, 320, 0, 1), (1280, 1280, 0, 0), (320, 2880, 0, 0), (1280, 5120, 0, 1), (512, 4608, 0, 0)]
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 1, 2, 23]
 for (N, K, geglu, res) in shapes:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
@@ -24,7 +26,7 @@ for (N, K, geglu, res) in shapes:
             if res: g.R, g.ldr = R.data_ptr(), nout
             g.zeros = ops.zeros_page(a.device).data_ptr(); g.C, g.ldc = out.data_ptr(), nout; g.epi_flags = geglu | bits; g.tile_cfg = cfg
             best = 1e9
-            for _ in range(4):
+            for _ in range(6):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record(); rc = L.lib.svd_gemm(C.byref(g), st); e.record(); e.synchronize()
                 best = min(best, s.elapsed_time(e))
