@@ -513,17 +513,34 @@ _UNIT_LUT = (np.arange(256) / 255.0).astype(np.float32)
 _PASS_LUT = ((np.arange(256) / 255.0).astype(np.float32) * np.float32(255.0)).astype(np.uint8)
 
 
-def vfi_process(video, vfi, video_len, out_size=(1280, 720), device="cuda"):
+def vfi_process(video, vfi, video_len, out_size=(1280, 720), device="cuda", group=None, sharded=False):
     """i2v_enhance_interface.vfi_process :30-61.  video: sequence of uint8 RGB frames [H, W, 3]; vfi: EMAVFI.
-    -> list of `video_len` PIL frames (input frame, interpolated frame, ..., last frame [twice when video_len is even]) at out_size."""
+    -> list of `video_len` PIL frames (input frame, interpolated frame, ..., last frame [twice when video_len is even]) at out_size.
+    sharded=True (inside an initialised torch.distributed job): the frame pairs are independent, so rank r interpolates pairs r, r + world,
+    ... and one all-gather of the uint8 middle frames (2.8 MB each at 720 x 1280) gives every rank the full video -- the reference asserts
+    a single device here (i2v_enhance_interface.py:26)."""
     from PIL import Image
     frames = [np.asarray(f)[:, :, :3] for f in video[: video_len // 2 + 1]]
     bgr = [torch.from_numpy(_UNIT_LUT[np.ascontiguousarray(f[:, :, ::-1])]).to(device) for f in frames]          # i / 255. -> fp32, BGR (:33-37)
+    n_pairs = len(frames) - 1
+    mid = lambda i: vfi.inference(bgr[i], bgr[i + 1], want_uint8=True)[1]
+    if sharded and n_pairs > 0:
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        per_rank = (n_pairs + world - 1) // world
+        H, W = frames[0].shape[:2]
+        mine = [mid(s * world + rank) if s * world + rank < n_pairs else torch.zeros((H, W, 3), dtype=torch.uint8, device=device)
+                for s in range(per_rank)]                                                                        # padded: equal contributions
+        send = torch.stack(mine, 0).contiguous()
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(recv, send, group=group)
+        mids = [recv[i % world][i // world] for i in range(n_pairs)]
+    else:
+        mids = [mid(i) for i in range(n_pairs)]
     out = []
-    for i in range(len(frames) - 1):
+    for i in range(n_pairs):
         out.append(_PASS_LUT[frames[i]])
-        _, u8 = vfi.inference(bgr[i], bgr[i + 1], want_uint8=True)
-        out.append(u8.cpu().numpy()[:, :, ::-1])
+        out.append(mids[i].cpu().numpy()[:, :, ::-1])
     out.append(_PASS_LUT[frames[-1]])
     if video_len % 2 == 0:
         out.append(_PASS_LUT[frames[-1]])

@@ -3,6 +3,7 @@
   * randomized blending: single-process product loop == oracle restatement (bit-exact) and the window-sharded
     all-gather version == single process, on 2 ranks;
   * CFG-pair exchange: each rank evaluates one CFG half, all-gather == the 2-batch evaluation;
+  * EMA-VFI frame pairs sharded over ranks (all-gather of the middle frames) == single process;
   * bench timing helper: max over ranks."""
 import os
 import random
@@ -68,9 +69,25 @@ def _worker(rank, world, port, out):
         full = torch.cat([net(x, cond[0]), net(x, cond[1])], 0)
         ex = parallel.CfgPairExchange()
         ok_cfg = torch.equal(ex.gather(net(x, cond[ex.half])), full)
+        # EMA-VFI: frame pairs sharded over the ranks, one all-gather of the uint8 middle frames == the single-process video
+        import numpy as np
+        from streamingt2v_amd.ema_vfi import vfi_process
+
+        class FakeVFI:                      # stands in for EMAVFI.inference (a GPU kernel path): any deterministic function of the pair
+            def inference(self, a, b, want_uint8=False):
+                m = (a * 0.25 + b * 0.75)
+                return m, (m * 255.0).to(torch.uint8)
+
+        rs = np.random.default_rng(11)
+        video = [rs.integers(0, 256, (8, 12, 3), dtype=np.uint8) for _ in range(6)]
+        ok_vfi = True
+        for n in (11, 12, 4):               # 5 pairs on 2 ranks (padded slot), even target length, 1 pair (rank 1 idle)
+            one = vfi_process(video[: (n + 1) // 2], FakeVFI(), n, out_size=(12, 8), device="cpu")
+            two = vfi_process(video[: (n + 1) // 2], FakeVFI(), n, out_size=(12, 8), device="cpu", sharded=True)
+            ok_vfi = ok_vfi and len(one) == len(two) == n and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(one, two))
         tmax = parallel.max_over_ranks(1.0 + rank)
         parallel.barrier()
-        out.put((rank, ok_blend, ok_blend5, ok_cfg, tmax, parallel.shard_items(5, rank, world)))
+        out.put((rank, ok_blend and ok_vfi, ok_blend5, ok_cfg, tmax, parallel.shard_items(5, rank, world)))
     finally:
         dist.destroy_process_group()
 
