@@ -184,3 +184,24 @@ def test_vfi_process_on_device(ops):
     for i, (a, b) in enumerate(zip(got, ref)):
         d = np.abs(np.asarray(a).astype(int) - np.asarray(b).astype(int))
         assert d.max() <= (0 if i in (0, 2, 4, 5) else (6 if ELEM == torch.bfloat16 else 2)), (i, d.max())
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 96, 1), (112, 112, 2), (32, 224, 1)])
+def test_vfi_network_other_sizes(ops, H, W, B):
+    """Other token-grid shapes than the golden case: /8 grids 8x12, 14x14 (no padding: no attention mask without shift), 4x28;
+    /16 grids 4x6, 7x7, 2x14 -- padding on one, both or no axis, batch 1 and 2 -- against the CPU oracle."""
+    from oracle import vfi_oracle as O
+    torch.set_grad_enabled(False)
+    model, sd, _, _, T = _tiny()
+    model.load_state_dict(sd, device=DEV)
+    g = torch.Generator(); g.manual_seed(H * 1000 + W)
+    low = torch.rand(B, 6, H // 8 + 2, W // 8 + 2, generator=g)
+    x = torch.nn.functional.interpolate(low, scale_factor=8, mode="bicubic", align_corners=False).clamp(0, 1)[:, :, 5:5 + H, 3:3 + W].contiguous()
+    cl = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    r = model.net_forward(cl(x[:, :3]).to(DEV), cl(x[:, 3:6]).to(DEV), B, H, W, want=True)
+    o = O.net_forward(sd, O.vfi_config(T["F"], T["depth"]), x)
+    for lvl in (3, 4):
+        t, C, h, w = r["af"][lvl]
+        _rel(f"af{lvl} {H}x{W}", t[:, :C], cl(o["af"][lvl]), 3e-2)
+    close(f"flow [px] {H}x{W}", r["fm"][:, :4], cl(o["flow"]), 0.2, 0.0)
+    close(f"pred {H}x{W}", r["pred"], cl(o["pred"]), 2.5e-2, 0.0)
