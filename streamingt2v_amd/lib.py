@@ -7,6 +7,11 @@ path never silently degrades to PyTorch ops or to the CPU oracle.
 import ctypes as C
 import os
 
+# torch FIRST: it ships its own libamdhip64.so and the host side hands torch's streams and device pointers to this library.  Loading
+# libsvdhip.so before torch binds it to the system /opt/rocm HIP runtime instead -- a second runtime in the process, whose first launch
+# fails with "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""), "libsvdhip.so"))   # probe: developer build with a reduced tile table
 
