@@ -495,16 +495,26 @@ class EMAVFI:
         return ops.vfi_merge(w0.contiguous(), w1.contiguous(), fm[:, 4:5], u)
 
     @torch.no_grad()
-    def inference(self, img0, img1, want_uint8=False):
-        """Trainer.Model.inference(img0, img1, TTA=True, fast_TTA=True) :84-94.  img0 / img1: fp32 [H, W, 3] in [0, 1] on the device.
+    def inference(self, img0, img1, TTA=True, fast_TTA=True, want_uint8=False):
+        """Trainer.Model.inference(img0, img1, TTA, timestep = cfg.timestep, fast_TTA) :84-101; the reference calls it with TTA=True,
+        fast_TTA=True (i2v_enhance_interface.py:46).  img0 / img1: fp32 [H, W, 3] in [0, 1] on the device.
+          fast_TTA        the pair and its 180-degree rotation as ONE batch of two, averaged            (:90-94)
+          TTA only        the same average from two separate forwards                                   (:99-101)
+          neither         one forward                                                                   (:96-98)
         -> the middle frame fp32 [H, W, 3] (and, with want_uint8, its (x * 255).astype(uint8) truncation, i2v_enhance_interface.py:46-47)."""
         assert self.loaded, "load_state_dict first"
         H, W = img0.shape[:2]
         rot = lambda t: t.flip(0).flip(1)                                                       # imgs.flip(2).flip(3) on NCHW
-        i0 = torch.stack([img0, rot(img0)]).reshape(2 * H * W, 3).float().contiguous()
-        i1 = torch.stack([img1, rot(img1)]).reshape(2 * H * W, 3).float().contiguous()
-        pred = self.net_forward(i0, i1, 2, H, W)
-        out, u8 = ops.vfi_tta_average(pred, H, W, want_uint8)
+        rows = lambda ts: torch.stack(ts).reshape(len(ts) * H * W, 3).float().contiguous()
+        if fast_TTA:
+            pred = self.net_forward(rows([img0, rot(img0)]), rows([img1, rot(img1)]), 2, H, W)
+        elif TTA:
+            pred = torch.cat([self.net_forward(rows([img0]), rows([img1]), 1, H, W), self.net_forward(rows([rot(img0)]), rows([rot(img1)]), 1, H, W)], 0)
+        else:
+            pred = self.net_forward(rows([img0]), rows([img1]), 1, H, W)
+            u8 = (pred * 255.0).to(torch.uint8).view(H, W, 3) if want_uint8 else None            # same truncation, plain cast
+            return (pred.view(H, W, 3), u8) if want_uint8 else pred.view(H, W, 3)
+        out, u8 = ops.vfi_tta_average(pred.contiguous(), H, W, want_uint8)
         return (out.view(H, W, 3), u8) if want_uint8 else out.view(H, W, 3)
 
 

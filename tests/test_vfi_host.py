@@ -90,3 +90,23 @@ def test_window_geometry_matches_oracle():
             a, b = window_geometry(h, w, 7, shift), O.window_masks(h, w, 7, shift)
             assert a[:2] == b[:2]
             assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2]))
+
+
+def test_vfi_inference_tta_modes(monkeypatch):
+    """Trainer.Model.inference :84-101: fast TTA, two-pass TTA and no TTA against the oracle's statement of each."""
+    import vfi_shim
+    torch.set_grad_enabled(False)
+    vfi_shim.install(monkeypatch)
+    model, sd, inp, x = _tiny()
+    model.load_state_dict(sd, device="cpu")
+    cfg = O.vfi_config(TINY_VFI["F"], TINY_VFI["depth"])
+    a, b = inp["img0"][0].permute(1, 2, 0).contiguous(), inp["img1"][0].permute(1, 2, 0).contiguous()
+    imgs = torch.cat((inp["img0"], inp["img1"]), 1)
+    plain = O.net_forward(sd, cfg, imgs)["pred"]
+    flipped = O.net_forward(sd, cfg, imgs.flip(2).flip(3))["pred"].flip(2).flip(3)
+    nchw = lambda t: t.permute(2, 0, 1)[None]
+    assert (nchw(model.inference(a, b, TTA=False, fast_TTA=False)) - plain).abs().max() <= 2e-4
+    assert (nchw(model.inference(a, b, TTA=True, fast_TTA=False)) - (plain + flipped) / 2).abs().max() <= 2e-4
+    assert (nchw(model.inference(a, b)) - O.inference_fast_tta(sd, cfg, inp["img0"], inp["img1"])).abs().max() <= 2e-4
+    m, u8 = model.inference(a, b, TTA=False, fast_TTA=False, want_uint8=True)
+    assert torch.equal(u8, (m * 255.0).to(torch.uint8))
