@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .params import Spec, check_state_dict
-from .video_model import BF16, _Conv, _dev_bf16, _dev_f32, _sigmoid, pack_conv3x3, pack_tconv3, pad_rows
+from .video_model import _Conv, _dev_bf16, _dev_f32, _sigmoid, pack_conv3x3, pack_tconv3
 
 
 class VaeConfig:
