@@ -58,3 +58,18 @@ def test_product_path_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/svdhip.h is the drop-in boundary: it must compile as C99 and as C++ on its own (no HIP / torch types in the signatures)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("gcc not available")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    src = tmp_path / "t.c"
+    src.write_text('#include "svdhip.h"\nint f(void) { struct svd_gemm_args a; (void)a; return SVD_OK; }\n')
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only"], ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-I", inc, str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
