@@ -50,23 +50,21 @@ class VFIConfig:
 
 
 def _pad_cols(t, width):
-    """[rows, c] -> [rows, width] zero-padded (data movement)."""
+    """[rows, c] -> [rows, width] zero-padded (data movement, one concatenation kernel)."""
     if t.shape[1] == width:
         return t.contiguous()
-    out = torch.zeros((t.shape[0], width), dtype=t.dtype, device=t.device)
-    out[:, : t.shape[1]] = t
-    return out
+    return torch.cat([t, torch.zeros((t.shape[0], width - t.shape[1]), dtype=t.dtype, device=t.device)], 1)
 
 
 def _cat_tokens(parts, width=None):
-    """parts: [(tokens [rows, >= c], c)] -> [rows, c32(sum c)]: the channel concatenation of torch.cat(..., 1) without the pad channels."""
+    """parts: [(tokens [rows, >= c], c)] -> [rows, c32(sum c)]: the channel concatenation of torch.cat(..., 1) without the pad channels
+    (one concatenation kernel: every output element is written once)."""
     total = sum(c for _, c in parts)
-    out = torch.zeros((parts[0][0].shape[0], width or c32(total)), dtype=parts[0][0].dtype, device=parts[0][0].device)
-    o = 0
-    for t, c in parts:
-        out[:, o:o + c] = t[:, :c]
-        o += c
-    return out
+    width = width or c32(total)
+    pieces = [t[:, :c] for t, c in parts]
+    if width > total:
+        pieces.append(torch.zeros((parts[0][0].shape[0], width - total), dtype=parts[0][0].dtype, device=parts[0][0].device))
+    return torch.cat(pieces, 1)
 
 
 class _Conv:
@@ -397,7 +395,7 @@ class EMAVFI:
         """MotionFormer.forward (:464-497).  imgs: fp32 [n*H*W, 3] (frame-0 images then frame-1 images).
         -> af: 5 x (tokens, C, h, w);  mf: 2 x (tokens [., md * depth], C, h, w) for stages 4, 5."""
         cfg = self.cfg
-        x, h, w = ops.to_elem(_pad_cols(imgs, 32)), H, W
+        x, h, w = _pad_cols(ops.to_elem(imgs.contiguous()), 32), H, W          # cast the 3 channels, then pad in 16 bit
         af, mf, xs = [], [], []
         for i in range(3):
             for m in self.stage[i]:

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--graph", action="store_true", help="also time a hipGraph replay of one inference (launch-overhead check)")
     a = ap.parse_args()
     from streamingt2v_amd import ops
     from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
@@ -42,6 +43,31 @@ def main():
     dt = (time.time() - t0) / a.pairs
     print(f"EMA-VFI {a.height}x{a.width} F=32 fast-TTA {a.dtype}: {dt * 1e3:.1f} ms per interpolated frame "
           f"({1 / dt:.2f} frames/s), peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB, finite={bool(torch.isfinite(out).all())}")
+
+
+    if a.graph:
+        import time as _t
+        t0 = _t.time()
+        for _ in range(a.pairs):
+            m.inference(f0, f1, want_uint8=True)
+        cpu_issue = (_t.time() - t0) / a.pairs                      # host time to ISSUE one inference (no sync)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.inference(f0, f1, want_uint8=True)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gout, gu8 = m.inference(f0, f1, want_uint8=True)
+        g.replay(); torch.cuda.synchronize()
+        t0 = _t.time()
+        for _ in range(a.pairs):
+            g.replay()
+        torch.cuda.synchronize()
+        dg = (_t.time() - t0) / a.pairs
+        print(f"host issue time {cpu_issue * 1e3:.1f} ms per inference; hipGraph replay {dg * 1e3:.1f} ms per interpolated frame "
+              f"({1 / dg:.2f} frames/s), identical={bool(torch.equal(gout, out))}")
 
 
 if __name__ == "__main__":
