@@ -134,3 +134,20 @@ def tiny_vfi_inputs():
     base = torch.nn.functional.interpolate(torch.rand(1, 3, H // 4 + 2, W // 4 + 2, generator=g), scale_factor=4, mode="bicubic",
                                            align_corners=False).clamp(0, 1)
     return dict(img0=base[:, :, 2:2 + H, 3:3 + W].contiguous(), img1=base[:, :, 4:4 + H, 1:1 + W].contiguous())
+
+
+# ---- the enhancer's pipeline call (code/i2v_enhance/pipeline_i2vgen_xl.py:607-935) around the tiny UNet: 10 frames of 72x128 pixels,
+#      two blending windows of 6 frames with overlap 2, key images of other sizes / aspect ratios, 10 DDIM steps at strength 0.35 (3 run) ----
+TINY_I2V_CALL = dict(H=72, W=128, n_frames=10, chunk=6, overlap=2, steps=10, strength=0.35, guidance=9.0, fps=38, gen_seed=8888, py_seed=33)
+
+
+def tiny_i2v_call_inputs():
+    import numpy as np
+    import PIL.Image
+    c = TINY_I2V_CALL
+    rs = np.random.default_rng(4)
+    frames = [rs.integers(0, 256, (c["H"], c["W"], 3), dtype=np.uint8) for _ in range(c["n_frames"])]
+    images = [PIL.Image.fromarray(rs.integers(0, 256, (150, 200, 3), dtype=np.uint8)), PIL.Image.fromarray(rs.integers(0, 256, (90, 300, 3), dtype=np.uint8))]
+    g = _gen(1)
+    cd, nt = TINY_I2V["cross_attention_dim"], TINY_I2V["text_tokens"]
+    return dict(frames=frames, images=images, prompt_embeds=torch.randn(1, nt, cd, generator=g), negative_prompt_embeds=torch.randn(1, nt, cd, generator=g))

@@ -266,3 +266,78 @@ class DDIM:
             x0 = (sample - b_t.sqrt() * model_out) / a_t.sqrt()
             eps = model_out
         return a_prev.sqrt() * x0 + (1 - a_prev).sqrt() * eps
+
+
+# ------------------------------------------------------------------------------------------------ the pipeline call
+def center_crop_wide(img, resolution):
+    """pipeline_i2vgen_xl.py:965-1000 (_center_crop_wide) for one PIL image."""
+    import PIL.Image
+    scale = min(img.size[0] / resolution[0], img.size[1] / resolution[1])
+    img = img.resize((round(img.width // scale), round(img.height // scale)), resample=PIL.Image.BOX)
+    x1, y1 = (img.width - resolution[0]) // 2, (img.height - resolution[1]) // 2
+    return img.crop((x1, y1, x1 + resolution[0], y1 + resolution[1]))
+
+
+def enhance_call(sd, images, frames, prompt_embeds, negative_prompt_embeds, vae, image_encoder, generator, py_random, *, height, width, chunk_size,
+                 overlap_size, num_inference_steps, strength, guidance_scale, target_fps=38, clip_mean=(0.48145466, 0.4578275, 0.40821073),
+                 clip_std=(0.26862954, 0.26130258, 0.27577711), crop_size=224, trace=None):
+    """I2VGenXLPipeline.__call__ (pipeline_i2vgen_xl.py:730-925) with output_type='latent', in the order the reference consumes its random
+    streams: per key image [CLIP embedding, then after all embeddings: VAE posterior sample of the wide crop], the video's posterior sample,
+    the SDEdit noise; one `random.randint` per blending window after the first, per DDIM step.
+    vae: .encode(x).latent_dist.sample(generator), .config.scaling_factor;  image_encoder(pixels).image_embeds.
+    trace (optional dict) receives the intermediates (conds per window, initial latents, timesteps)."""
+    import numpy as np
+    import PIL.Image
+    to_pt = lambda pil: torch.from_numpy(np.stack([np.array(p).astype(np.float32) / 255.0 for p in pil], 0).transpose(0, 3, 1, 2))
+    text = torch.cat([negative_prompt_embeds, prompt_embeds])                                     # :764-765  [uncond | cond]
+    mean, std = torch.tensor(clip_mean).view(1, 3, 1, 1), torch.tensor(clip_std).view(1, 3, 1, 1)
+    embs = []
+    for img in images:                                                                             # :771-780, _encode_image :349-383
+        sq = center_crop_wide(img, (width, width)).resize((crop_size, crop_size), PIL.Image.BILINEAR)
+        e = image_encoder((to_pt([sq]) - mean) / std).image_embeds.unsqueeze(1)
+        embs.append(torch.cat([torch.zeros_like(e), e]))
+    n_win = len(images)
+    lats = []
+    for img in images:                                                                             # :784-795, prepare_image_latents :479-511
+        wide = center_crop_wide(img, (width, height))
+        il = vae.encode(2.0 * to_pt([wide]) - 1.0).latent_dist.sample() * vae.config.scaling_factor   # NB: no generator (:486)
+        il = il.unsqueeze(2)
+        planes = [torch.ones_like(il[:, :, :1]) * ((i + 1) / (chunk_size - 1)) for i in range(chunk_size - 1)]
+        il = torch.cat([il] + planes, 2) if planes else il
+        lats.append(torch.cat([il] * 2))
+    fps = torch.tensor([target_fps, target_fps])
+    video = 2.0 * to_pt([PIL.Image.fromarray(np.asarray(f)) for f in frames]) - 1.0               # [F, 3, H, W]
+    sched = DDIM()
+    sched.set_timesteps(num_inference_steps)
+    t_start = max(num_inference_steps - min(int(num_inference_steps * strength), num_inference_steps), 0)   # get_timesteps :541-551
+    ts = sched.timesteps.tolist()[t_start:]
+    F_ = video.shape[0]
+    if F_ > 16:                                                                                    # prepare_video_latents :585-597
+        init = torch.cat([vae.encode(ch).latent_dist.sample(generator) for ch in torch.chunk(video, F_ // 16, 0)], 0)
+    else:
+        init = vae.encode(video).latent_dist.sample(generator)
+    init = vae.config.scaling_factor * init
+    noise = torch.randn(init.shape, generator=generator)
+    lat = sched.add_noise(init, noise, ts[0])
+    lat = lat[None].permute(0, 2, 1, 3, 4)                                                         # [1, 4, F, h, w]
+    if trace is not None:
+        b5 = lambda x: x[None].permute(0, 2, 1, 3, 4).clone()
+        trace.update(image_embeddings=embs, image_latents=lats, fps=fps, text=text, init_latents=lat.clone(), timesteps=ts, clean=b5(init), noise=b5(noise))
+    for t in ts:                                                                                   # :841-905
+        out = torch.empty_like(lat)
+        start = 0
+        for idx in range(n_win):
+            w = lat[:, :, start:start + chunk_size]
+            pred = unet(sd, torch.cat([w] * 2), torch.tensor(t), fps, lats[idx], embs[idx].squeeze(1), text)
+            pu, pc = pred.chunk(2)
+            pred = pu + guidance_scale * (pc - pu)
+            B, C, Fr, h, w_ = w.shape
+            fr = lambda x: x.permute(0, 2, 1, 3, 4).reshape(B * Fr, C, h, w_)
+            new = sched.step(fr(pred), t, fr(w))[None].reshape(B, Fr, C, h, w_).permute(0, 2, 1, 3, 4)
+            off = 0 if start == 0 or overlap_size == 0 else py_random.randint(0, overlap_size - 1)
+            out[:, :, start + off:start + chunk_size] = new[:, :, off:]
+            start += chunk_size - overlap_size
+        lat = out
+        if start + overlap_size > lat.shape[2]:
+            raise NotImplementedError("video does not divide into chunks")
+    return lat

@@ -6,7 +6,8 @@ consumes:
     window_conditioning(images,..)  :753-800                         per window: CLIP image embedding of the centre-cropped key image
                                                                      (zeros for the unconditional half), VAE latents of the image +
                                                                      frame-position-mask planes (:479-511), [negative | positive]
-                                                                     prompt embeddings, fps 16
+                                                                     prompt embeddings, fps 38 (the fork's `target_fps` default
+                                                                     :630, which i2v_enhance_interface.py:95-133 does not override)
     noise_like(latents)             randn_tensor(..., generator)     :605-606
     decode(latents)                 decode_latents :384-406          one frame at a time, (x / 2 + 0.5).clamp(0, 1) -> uint8
 
@@ -40,7 +41,7 @@ def frame_position_planes(image_latents, num_frames):
 
 
 class EnhanceCodec:
-    def __init__(self, vae, image_tower, text_tower=None, height=720, width=1280, target_fps=16, generator=None, device="cuda"):
+    def __init__(self, vae, image_tower, text_tower=None, height=720, width=1280, target_fps=38, generator=None, device="cuda"):
         """vae: temporal_ae.AutoencoderKL2D; image_tower: clip_vision.OpenCLIPVisionTower (loaded through
         hf_clip_vision_to_openclip_keys); text_tower: clip_text.CLIPTextTower or None when prompt embeddings are given directly."""
         self.vae, self.image_tower, self.text_tower = vae, image_tower, text_tower
@@ -86,14 +87,17 @@ class EnhanceCodec:
         pil = [self._to_pil(f) for f in frames]
         pil = [p if p.size == (self.w, self.h) else p.resize((self.w, self.h)) for p in pil]
         out = []
-        n = max(1, len(pil) // 16) if len(pil) > 16 else 1                      # torch.chunk(video, F // 16) for long videos (:586-595)
-        for idx in np.array_split(np.arange(len(pil)), n):
-            out.append(self.vae.encode_sample(self._pixels([pil[i] for i in idx]), self.gen))
+        n = len(pil) // 16 if len(pil) > 16 else 1                              # torch.chunk(video, F // 16) for long videos (:586-595):
+        size = -(-len(pil) // n)                                                # chunks of ceil(F / n) frames, the last one shorter
+        for a in range(0, len(pil), size):
+            out.append(self.vae.encode_sample(self._pixels(pil[a:a + size]), self.gen))
         lat = torch.cat(out, 0)                                                 # [F, 4, h, w]
         return lat.permute(1, 0, 2, 3)[None].contiguous()                       # [1, 4, F, h, w]
 
     def noise_like(self, latents):
-        return torch.randn(latents.shape, generator=self.gen, device=latents.device)
+        """randn_tensor of the FRAME-major shape [F, 4, h, w] the reference draws (:605-606), returned as [1, 4, F, h, w]."""
+        b, c, f, h, w = latents.shape
+        return torch.randn((b * f, c, h, w), generator=self.gen, device=latents.device).view(b, f, c, h, w).permute(0, 2, 1, 3, 4).contiguous()
 
     def window_conditioning(self, images, n_windows, window_len):
         """One conditioning dict per blending window (unconditional half first).  images: one key image per window (or a single
@@ -105,7 +109,7 @@ class EnhanceCodec:
             img = self._to_pil(images[i] if len(images) > 1 else images[0])
             emb = self.image_embedding(img)
             wide = center_crop_wide(img, (self.w, self.h))
-            il = frame_position_planes(self.vae.encode_sample(self._pixels([wide]), self.gen), window_len)
+            il = frame_position_planes(self.vae.encode_sample(self._pixels([wide]), None), window_len)   # sample() WITHOUT the generator (:486)
             conds.append(dict(fps=torch.tensor([self.fps, self.fps]), image_latents=torch.cat([il, il], 0),
                               image_embeddings=torch.cat([torch.zeros_like(emb), emb], 0), text=text))
         return conds

@@ -20,7 +20,7 @@ import torch
 # config.yaml values the reference's front end reads (inference_i2v.py:31-47, config.yaml:2,146-156, i2v_enhance_interface.py:82-131)
 DEFAULTS = dict(num_frames=200, out_fps=24, chunk_size=38, overlap_size=12, use_randomized_blending=False, seed=33,
                 num_frames_per_chunk=25, num_conditional_frames=7, num_steps=30, enhance_steps=30, enhance_strength=0.97,
-                enhance_guidance_scale=9.0, enhance_generator_seed=8888, enhance_height=720, enhance_width=1280,
+                enhance_guidance_scale=9.0, enhance_target_fps=38, enhance_generator_seed=8888, enhance_height=720, enhance_width=1280,
                 prompt="High Quality, HQ, detailed.",
                 negative_prompt="Distorted, blurry, discontinuous, Ugly, blurry, low resolution, motionless, static, disfigured, "
                                 "disconnected limbs, Ugly faces, incomplete arms")
@@ -186,14 +186,14 @@ class StreamingPipeline:
         if use_randomized_blending:
             starts, max_idx = enhance_windows(len(video), chunk_size, overlap_size)
             key_frames = [video[s] for s in starts]                              # 1st frame of every window, enhanced first
-            lat = codec.encode_video(key_frames)                                 # one window of len(starts) frames, no overlap
-            conds = codec.window_conditioning(images, 1, len(key_frames))
+            conds = codec.window_conditioning(images, 1, len(key_frames))         # the reference's order of random draws: image latents,
+            lat = codec.encode_video(key_frames)                                 # video posterior, SDEdit noise (pipeline_i2vgen_xl.py:784-829)
             images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng)))
             video = video[:max_idx]
         else:
             starts, chunk_size, overlap_size = [0], len(video), 0
-        lat = codec.encode_video(video)
         conds = codec.window_conditioning(images, len(starts), chunk_size)
+        lat = codec.encode_video(video)
         return codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng))
 
     def interpolate_video(self, video, dest_num_frames, **kwargs):
