@@ -151,3 +151,25 @@ def tiny_i2v_call_inputs():
     g = _gen(1)
     cd, nt = TINY_I2V["cross_attention_dim"], TINY_I2V["text_tokens"]
     return dict(frames=frames, images=images, prompt_embeds=torch.randn(1, nt, cd, generator=g), negative_prompt_embeds=torch.randn(1, nt, cd, generator=g))
+
+
+# ---- the autoregressive outer loop (code/diffusion_trainer/streaming_svd.py:293-356) with a stand-in chunk generator ----
+TINY_AR = dict(H=16, W=24, T=25, Tc=7, anchor=6, n_ar=2)
+
+
+def tiny_ar_chunk0():
+    """Chunk 0 as image_to_video hands it over (:388-394): PIL uint8 frames -> ToTensor -> * 2 - 1."""
+    g = _gen(606)
+    u8 = (torch.rand(TINY_AR["T"], 3, TINY_AR["H"], TINY_AR["W"], generator=g) * 255).round()
+    return u8 / 255.0 * 2.0 - 1
+
+
+def tiny_ar_generate(svd_input_frame, ctrl_frames, k):
+    """Stand-in for _generate_conditional_output: T frames in [-1, 1] that depend on the anchor frame, on every control frame (with its
+    position) and on the chunk counter -- any mistake in which frames are handed over changes the result."""
+    T = TINY_AR["T"]
+    ctrl = ctrl_frames[0]                                                   # [Tc, 3, H, W]
+    w = torch.linspace(0.5, 1.5, ctrl.shape[0]).view(-1, 1, 1, 1)
+    base = 0.6 * svd_input_frame + 0.4 * (ctrl * w).mean(0)
+    ramp = torch.linspace(-0.3, 0.3, T).view(T, 1, 1, 1) * (1 + 0.1 * k)
+    return torch.clamp(base[None] + ramp + 0.05 * torch.sin(7.0 * base[None] + k), -1.0, 1.0)

@@ -72,14 +72,25 @@ class StreamingSVD:
         n_ar = max(0, math.ceil((num_frames - T) / (T - Tc)))
         assert len(noises) >= 1 + n_ar
         c, uc = conditioner(image)
-        first = self._generate_initial_chunk(c, uc, noises[0])
+        first = self.quantize_like_pil(self._generate_initial_chunk(c, uc, noises[0]))
         video = self._autoregressive_generation(first, conditioner, n_ar, noises[1:], num_steps=num_steps)
         return video[:num_frames]
 
     @staticmethod
+    def quantize_like_pil(frames):
+        """Chunk 0 reaches the autoregressive loop through PIL (streaming_svd.py:388-394): the diffusers pipeline returns uint8 frames
+        ((x / 2 + 0.5).clamp(0, 1) * 255).round(), and `ToTensor()(frame) * 2.0 - 1` brings them back -- the first 25 frames, the anchor and
+        the first control frames are therefore 8-bit values.  [-1, 1] fp32 in, [-1, 1] fp32 on the 1/255 grid out (format conversion)."""
+        return ((frames / 2 + 0.5).clamp(0, 1) * 255.0).round() / 255.0 * 2.0 - 1
+
+    @staticmethod
     def extract_ctrl_frames(video, num_conditional_frames):
-        """Last frames of the previous chunk as [1, Tc, 3, H, W] (streaming_svd.py:263-290)."""
-        return video[-num_conditional_frames:][None].contiguous()
+        """Last frames of the previous chunk as [1, Tc, 3, H, W] (streaming_svd.py:263-290).  The reference first sends the chunk through
+        convert_range([-1, 1] -> [-1, 1]) (utils/result_processor.py:4-14): (v + 1) / 2 * 2 - 1 in fp32 is not the identity in the last bit,
+        and is reproduced here (7 frames, once per chunk) so that the hand-over is bit-identical."""
+        v = video[-num_conditional_frames:][None]
+        v = (v - (-1.0)) / 2.0
+        return (v * 2.0 + (-1.0)).contiguous()
 
     @torch.no_grad()
     def _autoregressive_generation(self, initial_generation, conditioner, n_autoregressive_generations, noises,

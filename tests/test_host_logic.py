@@ -98,7 +98,7 @@ def test_autoregressive_bookkeeping():
     out = m._autoregressive_generation(init, lambda a: ({"anchor": a}, {}), 3, [None] * 3)
     assert out.shape[0] == 25 + 3 * 18                       # ceil((N-25)/18) chunks, inference_i2v.py:179-184
     assert all(torch.equal(a, init[6]) for a, _ in seen)      # anchor fixed to the 7th frame of chunk 0
-    assert torch.equal(seen[0][1][0], init[-7:])              # first ctrl frames = tail of chunk 0
+    assert torch.allclose(seen[0][1][0], init[-7:], atol=2e-7)   # first ctrl frames = tail of chunk 0 (through the reference's range round trip)
     assert torch.allclose(seen[1][1][0, :, 0, 0, 0], 1.0 + torch.arange(18, 25) / 100.0)   # then tail of chunk 1
     assert torch.allclose(out[25:43, 0, 0, 0], 1.0 + torch.arange(7, 25) / 100.0)          # overlap frames dropped
 
@@ -458,3 +458,41 @@ def test_kornia_resize_restatement_properties():
     ref = F.conv2d(F.pad(big, (3, 3, 1, 1), mode="reflect"), k2[None, None])
     ref = F.interpolate(ref, size=(224, 224), mode="bicubic", align_corners=True)
     assert (kornia_resize_antialias(big, (224, 224)) - ref).abs().max() < 1e-5
+
+
+def test_autoregressive_loop_matches_reference_golden():
+    """streaming_svd.StreamingSVD._autoregressive_generation (product host logic) against the uint8 video of the reference's UNMODIFIED loop
+    (tests/golden/ar_loop_tiny.pt, oracle/make_golden_ar_loop.py): same stand-in chunk generator on both sides, so anchor / control-frame
+    hand-over, kept frames, concatenation and the final truncation (range oracle, bit-exact with the reference's IImage path) must agree."""
+    from oracle.cases import TINY_AR, tiny_ar_chunk0, tiny_ar_generate
+    from oracle.range_oracle import frames_to_uint8
+    import os
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ar_loop_tiny.pt"))
+    calls = []
+
+    class Host(StreamingSVD):
+        def __init__(self):
+            self.num_conditional_frames = TINY_AR["Tc"]
+
+        def _generate_conditional_output(self, c, uc, ctrl_frames, noise, num_steps=None):
+            calls.append((c.clone(), ctrl_frames.clone()))
+            return tiny_ar_generate(c, ctrl_frames, len(calls) - 1)
+
+    video = Host()._autoregressive_generation(tiny_ar_chunk0(), lambda anchor: (anchor, None), TINY_AR["n_ar"], [None] * TINY_AR["n_ar"],
+                                              anchor_index=TINY_AR["anchor"])
+    for k in range(TINY_AR["n_ar"]):
+        assert torch.equal(calls[k][0], g["anchors"][k]) and torch.equal(calls[k][1], g["ctrl"][k]), k
+    assert torch.equal(frames_to_uint8(video), g["video"])
+
+
+def test_chunk0_goes_through_uint8_like_the_reference():
+    """image_to_video :388-394: chunk 0 = ToTensor(PIL uint8 frame) * 2 - 1; every value sits on the 1/255 grid and survives a second pass."""
+    from oracle.cases import tiny_ar_chunk0
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(4, 3, 8, 8, generator=g) * 2.4 - 1.2
+    q = StreamingSVD.quantize_like_pil(x)
+    u8 = ((x / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8)                      # diffusers numpy_to_pil
+    assert torch.equal(q, u8.float() / 255.0 * 2.0 - 1)                                  # torchvision ToTensor, then * 2 - 1
+    assert torch.equal(StreamingSVD.quantize_like_pil(q), q) and torch.equal(StreamingSVD.quantize_like_pil(tiny_ar_chunk0()), tiny_ar_chunk0())
