@@ -173,3 +173,19 @@ def tiny_ar_generate(svd_input_frame, ctrl_frames, k):
     base = 0.6 * svd_input_frame + 0.4 * (ctrl * w).mean(0)
     ramp = torch.linspace(-0.3, 0.3, T).view(T, 1, 1, 1) * (1 + 0.1 * k)
     return torch.clamp(base[None] + ramp + 0.05 * torch.sin(7.0 * base[None] + k), -1.0, 1.0)
+
+
+# ---- i2v_enhance_interface.vfi_process (:30-61) around a stand-in interpolator ----
+def tiny_vfi_process_inputs():
+    """6 uint8 RGB frames [36, 64, 3] hitting every byte value (the pass-through round trip k / 255. -> fp32 -> * 255 -> uint8 loses some k)."""
+    import numpy as np
+    rs = np.random.default_rng(21)
+    frames = [rs.integers(0, 256, (36, 64, 3), dtype=np.uint8) for _ in range(6)]
+    frames[0].reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+    return frames
+
+
+def tiny_vfi_process_infer(I0, I2):
+    """stand-in for vfi.inference: asymmetric in (I0, I2) and in the channel order, values in [0, 1]; [1, 3, H, W] -> [1, 3, H, W]."""
+    w = torch.tensor([0.2, 0.5, 0.9]).view(1, 3, 1, 1)
+    return (0.35 * I0 + 0.65 * I2) * w + (1 - w) * I0.flip(3) * 0.5

@@ -109,3 +109,30 @@ def test_vfi_inference_tta_modes(monkeypatch):
     assert (nchw(model.inference(a, b)) - O.inference_fast_tta(sd, cfg, inp["img0"], inp["img1"])).abs().max() <= 2e-4
     m, u8 = model.inference(a, b, TTA=False, fast_TTA=False, want_uint8=True)
     assert torch.equal(u8, (m * 255.0).to(torch.uint8))
+
+
+def test_vfi_process_matches_reference_function_golden():
+    """ema_vfi.vfi_process against the output of the reference's UNMODIFIED i2v_enhance_interface.vfi_process (tests/golden/
+    vfi_process_tiny.pt, oracle/make_golden_vfi_process.py) around the same stand-in interpolator: the frames handed to `inference`
+    (bit-equal: BGR order, k / 255. in fp32) and every output frame at 1280 x 720 (compared on the stored 40-pixel grid)."""
+    from oracle.cases import tiny_vfi_process_infer, tiny_vfi_process_inputs
+    from streamingt2v_amd import ema_vfi
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "vfi_process_tiny.pt"))
+    seen = []
+
+    class Fake:
+        def inference(self, a, b, want_uint8=False):
+            nchw = lambda t: t.permute(2, 0, 1)[None]
+            seen.append((nchw(a).clone(), nchw(b).clone()))
+            m = tiny_vfi_process_infer(nchw(a), nchw(b))[0].permute(1, 2, 0).contiguous()
+            return m, (m * 255.0).to(torch.uint8)
+
+    for n in (7, 8):
+        seen.clear()
+        frames = ema_vfi.vfi_process(tiny_vfi_process_inputs()[: (n + 1) // 2], Fake(), n, device="cpu")
+        g = gold[n]
+        assert len(frames) == n and len(seen) == len(g["pairs"])
+        for (a, b), (ra, rb) in zip(seen, g["pairs"]):
+            assert torch.equal(a, ra) and torch.equal(b, rb)
+        sub = np.stack([np.asarray(f)[::40, ::40] for f in frames], 0)
+        assert all(f.size == (1280, 720) for f in frames) and np.array_equal(sub, g["sub"].numpy())
