@@ -189,3 +189,13 @@ def tiny_vfi_process_infer(I0, I2):
     """stand-in for vfi.inference: asymmetric in (I0, I2) and in the channel order, values in [0, 1]; [1, 3, H, W] -> [1, 3, H, W]."""
     w = torch.tensor([0.2, 0.5, 0.9]).view(1, 3, 1, 1)
     return (0.35 * I0 + 0.65 * I2) * w + (1 - w) * I0.flip(3) * 0.5
+
+
+# ---- i2v_enhance_interface.i2v_enhance_process (:86-138) around a recording stand-in pipeline ----
+def tiny_enhance_process_inputs(n_frames):
+    """([key image], n_frames distinct frames) as PIL images of 8 x 12 pixels (the function never looks at the pixels)."""
+    import numpy as np
+    import PIL.Image
+    rs = np.random.default_rng(77)
+    mk = lambda: PIL.Image.fromarray(rs.integers(0, 256, (8, 12, 3), dtype=np.uint8))
+    return [mk()], [mk() for _ in range(n_frames)]

@@ -496,3 +496,55 @@ def test_chunk0_goes_through_uint8_like_the_reference():
     u8 = ((x / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8)                      # diffusers numpy_to_pil
     assert torch.equal(q, u8.float() / 255.0 * 2.0 - 1)                                  # torchvision ToTensor, then * 2 - 1
     assert torch.equal(StreamingSVD.quantize_like_pil(q), q) and torch.equal(StreamingSVD.quantize_like_pil(tiny_ar_chunk0()), tiny_ar_chunk0())
+
+
+def test_enhance_video_structure_matches_reference_process(monkeypatch):
+    """pipeline.StreamingPipeline.enhance_video against the recorded calls of the reference's UNMODIFIED i2v_enhance_process
+    (tests/golden/enhance_process_tiny.pt, oracle/make_golden_enhance_process.py): key frames, the key-frame pre-pass whose decoded output
+    becomes the per-window images, truncation to whole windows, chunk / overlap / window length, strength, 30 steps, guidance 9."""
+    import os
+    import zlib
+    import numpy as np
+    from oracle.cases import tiny_enhance_process_inputs
+    from streamingt2v_amd import enhance, pipeline
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "enhance_process_tiny.pt"))
+    crc = lambda f: zlib.crc32(np.ascontiguousarray(np.asarray(f)).tobytes())
+    log = []
+
+    class Codec:
+        def window_conditioning(self, images, n, window_len):
+            log.append(dict(image=[crc(i) for i in images], num_frames=window_len, n_windows=n))
+            return [dict() for _ in range(n)]
+
+        def encode_video(self, frames):
+            log[-1]["video"] = [crc(f) for f in frames]
+            return list(frames)
+
+        def noise_like(self, lat):
+            return None
+
+        def decode(self, lat):
+            return [255 - np.asarray(f) for f in lat]
+
+    class Enhancer:
+        def __init__(self, unet, scheduler=None, guidance_scale=None, num_inference_steps=None, strength=None):
+            self.kw = dict(guidance_scale=guidance_scale, num_inference_steps=num_inference_steps, strength=strength)
+
+        def denoise(self, lat, noise, conds, chunk_size, overlap_size, rng=None, group=None):
+            log[-1].update(self.kw, chunk_size=chunk_size, overlap_size=overlap_size, n_conds=len(conds))
+            return lat
+
+    monkeypatch.setattr(enhance, "I2VEnhancer", Enhancer)
+    pipe = object.__new__(pipeline.StreamingPipeline)
+    pipe.cfg, pipe.enhancer_unet, pipe.enhance_codec = dict(pipeline.DEFAULTS), object(), Codec()
+    for name, n_frames, rb, chunk, overlap in (("blend_100", 100, True, 38, 12), ("blend_90", 90, True, 38, 12), ("plain_100", 100, False, 100, 0)):
+        image, video = tiny_enhance_process_inputs(n_frames)
+        log.clear()
+        out = pipe.enhance_video(image[0], video, chunk_size=chunk, overlap_size=overlap, strength=0.97, use_randomized_blending=rb)
+        ref = gold[name]
+        assert len(log) == len(ref["calls"]), name
+        for got, want in zip(log, ref["calls"]):
+            for k in ("image", "video", "chunk_size", "overlap_size", "num_frames", "strength", "num_inference_steps", "guidance_scale"):
+                assert got[k] == want[k], (name, k)
+            assert got["n_conds"] == got["n_windows"] == len(want["image"])
+        assert [crc(f) for f in out] == ref["out"], name
