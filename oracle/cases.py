@@ -199,3 +199,13 @@ def tiny_enhance_process_inputs(n_frames):
     rs = np.random.default_rng(77)
     mk = lambda: PIL.Image.fromarray(rs.integers(0, 256, (8, 12, 3), dtype=np.uint8))
     return [mk()], [mk() for _ in range(n_frames)]
+
+
+# ---- inference_i2v.StreamingPipeline.enhance_video (:192-209): image handling in front of the enhancer ----
+def tiny_frontend_enhance_inputs():
+    """(key image uint8 [576, 1024, 3], video uint8 [3, 576, 1024, 3]): smooth content so that the resampling filter matters."""
+    g = _gen(909)
+    low = torch.rand(4, 3, 18, 32, generator=g)
+    up = torch.nn.functional.interpolate(low, size=(576, 1024), mode="bicubic", align_corners=False).clamp(0, 1)
+    u8 = (up * 255).round().to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    return u8[0], u8[1:]

@@ -113,6 +113,16 @@ def load_enhancer(folder, device="cuda", variant="fp16", generator=None):
     return unet, codec
 
 
+def resize_key_image(image, width=1280, height=720):
+    """inference_i2v.py:193-194: the key image enters the enhancer as IImage(image).resize((720, 1280)) -- PIL BICUBIC to width x height
+    (skipped when it already has that size, lib/farancia/libimage/iimage.py:169-192) -- before `_center_crop_wide` sees it.  Already
+    enhanced key frames (the second stage of randomized blending) have the target size and pass through."""
+    import numpy as np
+    import PIL.Image
+    img = image if isinstance(image, PIL.Image.Image) else PIL.Image.fromarray(np.asarray(image))
+    return img if img.size == (width, height) else img.resize((width, height), resample=PIL.Image.BICUBIC)
+
+
 def num_autoregressive_generations(num_frames, frames_per_chunk=25, num_conditional_frames=7):
     """inference_i2v.py:182-186."""
     return max(0, math.ceil((num_frames - frames_per_chunk) / (frames_per_chunk - num_conditional_frames)))
@@ -182,7 +192,7 @@ class StreamingPipeline:
                           strength=strength)
         rng = random.Random(c["seed"])
         video = list(video)
-        images = [image]
+        images = [resize_key_image(image, getattr(codec, "w", c["enhance_width"]), getattr(codec, "h", c["enhance_height"]))]
         if use_randomized_blending:
             starts, max_idx = enhance_windows(len(video), chunk_size, overlap_size)
             key_frames = [video[s] for s in starts]                              # 1st frame of every window, enhanced first

@@ -512,6 +512,8 @@ def test_enhance_video_structure_matches_reference_process(monkeypatch):
     log = []
 
     class Codec:
+        w, h = 12, 8                                  # the stand-in frames' size: the front-end key-image resize is a no-op here
+
         def window_conditioning(self, images, n, window_len):
             log.append(dict(image=[crc(i) for i in images], num_frames=window_len, n_windows=n))
             return [dict() for _ in range(n)]
@@ -548,3 +550,31 @@ def test_enhance_video_structure_matches_reference_process(monkeypatch):
                 assert got[k] == want[k], (name, k)
             assert got["n_conds"] == got["n_windows"] == len(want["image"])
         assert [crc(f) for f in out] == ref["out"], name
+
+
+def test_front_end_image_handling_matches_reference_enhance_video():
+    """What inference_i2v.StreamingPipeline.enhance_video (unmodified, tests/golden/frontend_enhance_tiny.pt) hands the enhancement pipeline:
+    key image via IImage.resize (BICUBIC to 1280 x 720), frames via PIL's default resize -- vs pipeline.resize_key_image and
+    EnhanceCodec.encode_video's frame resize (observed through a recording VAE stand-in)."""
+    import os
+    import numpy as np
+    from oracle.cases import tiny_frontend_enhance_inputs
+    from streamingt2v_amd.enhance_codec import EnhanceCodec
+    from streamingt2v_amd.pipeline import resize_key_image
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_enhance_tiny.pt"))
+    image, video = tiny_frontend_enhance_inputs()
+    key = resize_key_image(image)
+    assert key.size == (1280, 720) and np.array_equal(np.asarray(key)[::40, ::40], g["image"][0].numpy())
+    assert resize_key_image(key) is key
+    seen = []
+
+    class Vae:
+        def encode_sample(self, x, generator=None):
+            seen.append(x.clone())
+            return torch.zeros(x.shape[0], 4, x.shape[2] // 8, x.shape[3] // 8)
+
+    EnhanceCodec(Vae(), None, None, device="cpu").encode_video(list(video))
+    px = torch.cat(seen, 0)                                                           # [F, 3, 720, 1280] in [-1, 1]
+    back = ((px + 1.0) * 127.5).round().to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    for i in range(len(video)):
+        assert np.array_equal(back[i][::40, ::40], g["video"][i].numpy()), i
