@@ -209,3 +209,27 @@ def tiny_frontend_enhance_inputs():
     up = torch.nn.functional.interpolate(low, size=(576, 1024), mode="bicubic", align_corners=False).clamp(0, 1)
     u8 = (up * 255).round().to(torch.uint8).permute(0, 2, 3, 1).numpy()
     return u8[0], u8[1:]
+
+
+# ---- stage-1 conditioning (streaming_svd.py:155-221 + GeneralConditioner, config.yaml:160-218) with linear stand-ins for the networks ----
+TINY_SVD_COND = dict(H=32, W=48, T=25, Tc=7, seed=4711)
+
+
+def fake_clip_embed(img):
+    """stand-in for the OpenCLIP image tower: [b, 3, H, W] in [-1, 1] -> [b, 1024]."""
+    g = _gen(1001)
+    proj = torch.randn(3 * 4 * 4, 1024, generator=g) * 0.2
+    return torch.nn.functional.adaptive_avg_pool2d(img.float(), 4).flatten(1) @ proj.to(img.device)
+
+
+def fake_cond_encode(x):
+    """stand-in for AutoencoderKLModeOnly.encode: [b, 3, H, W] -> [b, 4, H/8, W/8]."""
+    g = _gen(1002)
+    mix = (torch.randn(4, 3, generator=g) * 0.7).to(x.device)
+    return torch.einsum("oc,bchw->bohw", mix, torch.nn.functional.avg_pool2d(x.float(), 8))
+
+
+def tiny_svd_cond_inputs():
+    g = _gen(1003)
+    c = TINY_SVD_COND
+    return dict(frame=torch.rand(3, c["H"], c["W"], generator=g) * 2 - 1, ctrl_frames=torch.rand(1, c["Tc"], 3, c["H"], c["W"], generator=g) * 2 - 1)

@@ -578,3 +578,25 @@ def test_front_end_image_handling_matches_reference_enhance_video():
     back = ((px + 1.0) * 127.5).round().to(torch.uint8).permute(0, 2, 3, 1).numpy()
     for i in range(len(video)):
         assert np.array_equal(back[i][::40, ::40], g["video"][i].numpy()), i
+
+
+def test_svd_conditioner_matches_reference_conditioning_path(monkeypatch):
+    """conditioner.SVDConditioner against what the reference's UNMODIFIED _generate_conditional_output + GeneralConditioner + get_batch_sgm
+    hand the sampler (tests/golden/svd_conditioning_tiny.pt, oracle/make_golden_conditioner.py; OpenCLIP tower and VAE encoder replaced by the
+    same linear stand-ins on both sides, the CLIP preprocessing -- which lives inside the replaced tower -- switched off)."""
+    import os
+    from oracle.cases import TINY_SVD_COND as cfg, fake_clip_embed, fake_cond_encode, tiny_svd_cond_inputs
+    from streamingt2v_amd.conditioner import SVDConditioner
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "svd_conditioning_tiny.pt"))
+    monkeypatch.setattr(SVDConditioner, "clip_preprocess", staticmethod(lambda img: img))
+    cond = SVDConditioner(fake_clip_embed, fake_cond_encode, num_frames=cfg["T"], generator=None)
+    torch.manual_seed(cfg["seed"])                                     # cond_frames = image + 0.02 * rand_like(image): global stream (:174)
+    c, uc = cond(tiny_svd_cond_inputs()["frame"])
+    for d, gd in ((c, g["c"]), (uc, g["uc"])):
+        for k in ("crossattn", "concat", "vector"):
+            assert d[k].shape[0] == cfg["T"] and tuple(d[k].shape[1:]) == tuple(gd[k].shape[1:]), k
+            assert all(torch.equal(d[k][0], d[k][i]) for i in range(1, cfg["T"]))
+            assert (d[k][:2] - gd[k]).abs().max() <= 1e-6, (k, (d[k][:2] - gd[k]).abs().max())
+    assert g["randn_shape"] == (cfg["T"], 4, cfg["H"] // 8, cfg["W"] // 8) and g["ctrl_equal"]
+    assert g["extra"]["batch_size"] == 2 and g["extra"]["num_conditional_frames"] == cfg["Tc"] and g["extra"]["num_video_frames"] == cfg["T"]
+    assert tuple(g["extra"]["image_only_indicator"].shape) == (2, cfg["T"]) and not g["extra"]["image_only_indicator"].any()
