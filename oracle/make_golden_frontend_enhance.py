@@ -55,6 +55,14 @@ def main():
                    sizes=[i.size for i in kw["image"]] + [f.size for f in kw["video"]])
         return types.SimpleNamespace(frames=[[PIL.Image.fromarray(np.asarray(f)) for f in kw["video"]]])
 
+    # the trainer-side input resize (utils/inference_utils.resize_and_keep, streaming_svd.py:383) == pipeline.resize_and_keep
+    from utils.inference_utils import resize_and_keep as ref_resize
+    from streamingt2v_amd.pipeline import resize_and_keep
+    rs = np.random.default_rng(3)
+    for (h, w) in ((1080, 1920), (300, 533), (720, 1281)):
+        a = rs.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(np.asarray(ref_resize(PIL.Image.fromarray(a))), resize_and_keep(a)), (h, w)
+    print("[front end] pipeline.resize_and_keep == the reference's resize_and_keep on 3 sizes")
     bare = types.SimpleNamespace(use_memopt=False)
     out = mod.StreamingPipeline.enhance_video(bare, image, video, enhance_pipeline=pipeline, enhance_generator=None, chunk_size=len(video),
                                               overlap_size=0, strength=0.97, use_randomized_blending=False)

@@ -113,6 +113,16 @@ def load_enhancer(folder, device="cuda", variant="fp16", generator=None):
     return unet, codec
 
 
+def resize_and_keep(image, height=576):
+    """utils/inference_utils.py:36-41, applied to the input image by the trainer's image_to_video (streaming_svd.py:381-383): PIL default
+    (BICUBIC) resize to `height` rows keeping the aspect ratio, width truncated to an int.  uint8 [H, W, 3] / PIL in, uint8 array out."""
+    import numpy as np
+    import PIL.Image
+    img = image if isinstance(image, PIL.Image.Image) else PIL.Image.fromarray(np.asarray(image))
+    wsize = int(float(img.size[0]) * (height / float(img.size[1])))
+    return np.asarray(img.resize((wsize, height)))
+
+
 def resize_key_image(image, width=1280, height=720):
     """inference_i2v.py:193-194: the key image enters the enhancer as IImage(image).resize((720, 1280)) -- PIL BICUBIC to width x height
     (skipped when it already has that size, lib/farancia/libimage/iimage.py:169-192) -- before `_center_crop_wide` sees it.  Already
@@ -155,17 +165,22 @@ class StreamingPipeline:
 
     @classmethod
     def from_checkpoint(cls, path, device="cuda", **kw):
+        kw.setdefault("input_height", 576)
         return cls(*load_streamingsvd_checkpoint(path, device=device), **kw)
 
     # ------------------------------------------------------------------------------------------ stage 1
     def image_to_video(self, image, num_frames, seed=None, **kwargs):
-        """image: uint8 [H, W, 3] (numpy or tensor) at 576x1024 (the reference's datamodule resizes before this point) or fp32
-        [3, H, W] in [-1, 1].  Returns uint8 [num_frames, H, W, 3] like trainer.generated_video[:num_frames]."""
+        """image: uint8 [H, W, 3] (numpy or tensor; with `input_height=576` -- what `from_checkpoint` configures -- it is brought to 576 rows
+        by `resize_and_keep` and must then be 1024 wide, like streaming_svd.py:381-384) or fp32 [3, H, W] in [-1, 1] (used as is).
+        Returns uint8 [num_frames, H, W, 3] like trainer.generated_video[:num_frames]."""
         if self.conditioner is None:
             raise NotImplementedError("image_to_video needs conditioner(frame) -> (c, uc): the OpenCLIP image tower + VAE encoder of "
                                       "the reference's GeneralConditioner are not part of the MI355X path (SURVEY.md 8f N4)")
         img = torch.as_tensor(image)
         if img.dtype == torch.uint8:
+            if self.cfg.get("input_height"):                                     # 576 for the shipped model (from_checkpoint's default)
+                img = torch.as_tensor(resize_and_keep(img.cpu().numpy(), self.cfg["input_height"]).copy())
+                assert img.shape[1] == self.cfg["input_height"] * 16 // 9, f"input image must be 16:9 (got {tuple(img.shape)} after resize_and_keep)"
             img = img.to(self.device).permute(2, 0, 1).float() / 127.5 - 1.0
         img = img.to(self.device, torch.float32)
         c = self.cfg

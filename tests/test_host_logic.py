@@ -600,3 +600,16 @@ def test_svd_conditioner_matches_reference_conditioning_path(monkeypatch):
     assert g["randn_shape"] == (cfg["T"], 4, cfg["H"] // 8, cfg["W"] // 8) and g["ctrl_equal"]
     assert g["extra"]["batch_size"] == 2 and g["extra"]["num_conditional_frames"] == cfg["Tc"] and g["extra"]["num_video_frames"] == cfg["T"]
     assert tuple(g["extra"]["image_only_indicator"].shape) == (2, cfg["T"]) and not g["extra"]["image_only_indicator"].any()
+
+
+def test_resize_and_keep_matches_pil_semantics():
+    """pipeline.resize_and_keep = utils/inference_utils.py:36-41: PIL default (BICUBIC) resize to 576 rows, width int(w * 576 / h)."""
+    import numpy as np
+    import PIL.Image
+    from streamingt2v_amd.pipeline import resize_and_keep
+    rs = np.random.default_rng(3)
+    for (h, w) in ((1080, 1920), (576, 1024), (300, 533), (720, 1281)):
+        a = rs.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out = resize_and_keep(a)
+        wsize = int(float(w) * (576 / float(h)))
+        assert out.shape == (576, wsize, 3) and np.array_equal(out, np.asarray(PIL.Image.fromarray(a).resize((wsize, 576))))
