@@ -113,6 +113,18 @@ def load_enhancer(folder, device="cuda", variant="fp16", generator=None):
     return unet, codec
 
 
+def load_vfi(path_or_state_dict, device="cuda", cfg=None):
+    """EMA-VFI from the reference's ``ours.pkl`` (i2v_enhance_interface.vfi_init :15-27: init_model_config(F=32, depth=[2,2,2,4,4]),
+    Trainer.Model.load_model strips ``module.`` and drops the cached attn_mask / HW buffers)."""
+    from .ema_vfi import EMAVFI
+    sd = path_or_state_dict
+    if isinstance(sd, str):
+        sd = torch.load(sd, map_location="cpu")
+    if any(k.startswith("module.") for k in sd):
+        sd = EMAVFI.convert_checkpoint(sd)
+    return EMAVFI(cfg).load_state_dict(sd, device=device)
+
+
 def resize_and_keep(image, height=576):
     """utils/inference_utils.py:36-41, applied to the input image by the trainer's image_to_video (streaming_svd.py:381-383): PIL default
     (BICUBIC) resize to `height` rows keeping the aspect ratio, width truncated to an int.  uint8 [H, W, 3] / PIL in, uint8 array out."""
@@ -162,6 +174,24 @@ class StreamingPipeline:
         self.num_frames, self.out_fps = c["num_frames"], c["out_fps"]
         self.use_randomized_blending, self.chunk_size, self.overlap_size = c["use_randomized_blending"], c["chunk_size"], c["overlap_size"]
         self.device = unet.device
+
+    @classmethod
+    def from_pretrained(cls, streamingsvd_ckpt, i2vgen_folder=None, vfi_ckpt=None, device="cuda", **kw):
+        """Everything inference_i2v.StreamingPipeline.init_model assembles (:125-165), from the same three artefacts: the StreamingSVD
+        checkpoint (UNet + ControlNet + decoder + stage-1 conditioner), the diffusers-format i2vgen-xl folder, EMA-VFI's ours.pkl."""
+        sd = streamingsvd_ckpt
+        if isinstance(sd, str):
+            if sd.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                sd = load_file(sd)
+            else:
+                sd = torch.load(sd, map_location="cpu")["state_dict"]
+        kw.setdefault("conditioner", load_conditioner(sd, device=device))
+        if i2vgen_folder is not None:
+            kw["enhancer_unet"], kw["enhance_codec"] = load_enhancer(i2vgen_folder, device=device)
+        if vfi_ckpt is not None:
+            kw["vfi"] = load_vfi(vfi_ckpt, device=device)
+        return cls.from_checkpoint(sd, device=device, **kw)
 
     @classmethod
     def from_checkpoint(cls, path, device="cuda", **kw):

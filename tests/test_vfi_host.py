@@ -136,3 +136,19 @@ def test_vfi_process_matches_reference_function_golden():
             assert torch.equal(a, ra) and torch.equal(b, rb)
         sub = np.stack([np.asarray(f)[::40, ::40] for f in frames], 0)
         assert all(f.size == (1280, 720) for f in frames) and np.array_equal(sub, g["sub"].numpy())
+
+
+def test_load_vfi_from_reference_style_checkpoint(tmp_path):
+    """pipeline.load_vfi: the shipped ours.pkl stores DDP keys (``module.``) plus cached attn_mask / HW buffers (Trainer.load_model :36-47)."""
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    cfg = VFIConfig(F=TINY_VFI["F"], depth=TINY_VFI["depth"])
+    sd = vfi_weights(EMAVFI(cfg).spec())
+    ckpt = {"module." + k: v for k, v in sd.items()}
+    ckpt["module.feature_bone.block4.1.attn_mask"] = torch.zeros(4, 49, 49)
+    ckpt["module.feature_bone.block4.1.HW"] = torch.tensor([196.0])
+    path = str(tmp_path / "ours.pkl")
+    torch.save(ckpt, path)
+    m = P.load_vfi(path, device="cpu", cfg=cfg)
+    assert m.loaded and m.device == "cpu"
+    assert P.load_vfi(sd, device="cpu", cfg=cfg).loaded                   # an already converted state_dict loads too
