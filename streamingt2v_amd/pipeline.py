@@ -186,12 +186,15 @@ class StreamingPipeline:
                 sd = load_file(sd)
             else:
                 sd = torch.load(sd, map_location="cpu")["state_dict"]
-        kw.setdefault("conditioner", load_conditioner(sd, device=device))
+        cfgs = {k: kw.pop(k, None) for k in ("unet_cfg", "vae_cfg", "clip_cfg", "cond_vae_cfg", "vfi_cfg")}   # non-default sizes (tests)
+        kw.setdefault("conditioner", load_conditioner(sd, device=device, clip_cfg=cfgs["clip_cfg"], vae_cfg=cfgs["cond_vae_cfg"],
+                                                      num_frames=kw.get("num_frames_per_chunk", DEFAULTS["num_frames_per_chunk"])))
         if i2vgen_folder is not None:
             kw["enhancer_unet"], kw["enhance_codec"] = load_enhancer(i2vgen_folder, device=device)
         if vfi_ckpt is not None:
-            kw["vfi"] = load_vfi(vfi_ckpt, device=device)
-        return cls.from_checkpoint(sd, device=device, **kw)
+            kw["vfi"] = load_vfi(vfi_ckpt, device=device, cfg=cfgs["vfi_cfg"])
+        kw.setdefault("input_height", 576)
+        return cls(*load_streamingsvd_checkpoint(sd, device=device, unet_cfg=cfgs["unet_cfg"], vae_cfg=cfgs["vae_cfg"]), **kw)
 
     @classmethod
     def from_checkpoint(cls, path, device="cuda", **kw):

@@ -613,3 +613,30 @@ def test_resize_and_keep_matches_pil_semantics():
         out = resize_and_keep(a)
         wsize = int(float(w) * (576 / float(h)))
         assert out.shape == (576, wsize, 3) and np.array_equal(out, np.asarray(PIL.Image.fromarray(a).resize((wsize, 576))))
+
+
+def test_from_pretrained_assembles_stage1_conditioner_and_vfi():
+    """StreamingPipeline.from_pretrained on a tiny checkpoint with the reference's key prefixes (UNet, ControlNet, decoder, OpenCLIP tower,
+    cond-frame encoder) plus an EMA-VFI state_dict: every stage object is built and wired (CPU: construction only)."""
+    from oracle import cases
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.clip_vision import ClipVisionConfig, OpenCLIPVisionTower
+    from streamingt2v_amd.conditioner import SVDConditioner
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder, VaeConfig, VideoDecoder
+    from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    tu, tv = cases.TINY_UNET, cases.TINY_VAE
+    ucfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"],
+                      channel_mult=tu["channel_mult"], conditioning_embedding_out_channels=tu["cond_embed"])
+    vcfg, ccfg, ecfg = VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]), ClipVisionConfig(width=320, layers=1, heads=4, embed_dim=1024), VaeConfig(32, (1, 1, 1, 2), 1)
+    fcfg = VFIConfig(F=cases.TINY_VFI["F"], depth=cases.TINY_VFI["depth"])
+    sd = {}
+    for prefix, mod, seed in ((P.CKPT_PREFIXES["unet"], VideoUNet(ucfg), 1), (P.CKPT_PREFIXES["controlnet"], ControlNet(ucfg), 2),
+                              (P.CKPT_PREFIXES["decoder"], VideoDecoder(vcfg), 3), (P.CKPT_PREFIXES["clip"], OpenCLIPVisionTower(ccfg), 4),
+                              (P.CKPT_PREFIXES["cond_encoder"], CondFrameEncoder(ecfg), 5)):
+        sd.update({prefix + k: v for k, v in init_by_name(mod.spec(), seed=seed).items()})
+    pipe = P.StreamingPipeline.from_pretrained(sd, vfi_ckpt=cases.vfi_weights(EMAVFI(fcfg).spec()), device="cpu", unet_cfg=ucfg, vae_cfg=vcfg,
+                                               clip_cfg=ccfg, cond_vae_cfg=ecfg, vfi_cfg=fcfg, num_frames_per_chunk=tu["T"], num_conditional_frames=tu["Tc"])
+    assert isinstance(pipe.conditioner, SVDConditioner) and pipe.conditioner.T == tu["T"] and isinstance(pipe.vfi, EMAVFI) and pipe.vfi.loaded
+    assert pipe.cfg["input_height"] == 576 and pipe.enhancer_unet is None
