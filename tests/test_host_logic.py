@@ -640,3 +640,37 @@ def test_from_pretrained_assembles_stage1_conditioner_and_vfi():
                                                clip_cfg=ccfg, cond_vae_cfg=ecfg, vfi_cfg=fcfg, num_frames_per_chunk=tu["T"], num_conditional_frames=tu["Tc"])
     assert isinstance(pipe.conditioner, SVDConditioner) and pipe.conditioner.T == tu["T"] and isinstance(pipe.vfi, EMAVFI) and pipe.vfi.loaded
     assert pipe.cfg["input_height"] == 576 and pipe.enhancer_unet is None
+
+
+def test_defaults_match_reference_config_values():
+    """The product's hard-coded defaults against the values read from the reference's config.yaml (tests/golden/config_values.json,
+    oracle/make_golden_config.py)."""
+    import inspect
+    import json
+    import os
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.sampling import AlignYourSteps, EulerEDMSampler, VScalingWithEDMcNoise
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    from streamingt2v_amd.temporal_ae import VaeConfig
+    from streamingt2v_amd.video_model import UNetConfig
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_values.json")) as f:
+        g = json.load(f)
+    u, n = UNetConfig(), g["network"]
+    for k in ("in_channels", "model_channels", "out_channels", "num_res_blocks", "context_dim", "adm_in_channels", "num_head_channels", "controlnet_mode"):
+        assert getattr(u, k) == n[k], k
+    assert list(u.attention_resolutions) == n["attention_resolutions"] and list(u.channel_mult) == n["channel_mult"]
+    assert list(u.conditioning_embedding_out_channels) == g["controlnet"]["conditioning_embedding_out_channels"]
+    assert n["use_apm"] is False and n["merging_mode"] == "attention_cross_attention" and n["transformer_depth"] == 1      # what the kernels assume
+    s = EulerEDMSampler()
+    sm = g["sampler"]
+    assert s.num_steps == sm["num_steps"] and isinstance(s.discretization, AlignYourSteps) and s.discretization.sigma_max == sm["sigma_max"]
+    assert s.guider.num_frames == sm["num_frames"] and float(s.guider.scale[0]) == sm["min_scale"] and float(s.guider.scale[-1]) == sm["max_scale"]
+    assert (sm["s_churn"], sm["s_tmin"], sm["s_noise"]) == (0.0, 0.0, 1.0)            # the plain Euler step the product implements
+    assert isinstance(s.scaling, VScalingWithEDMcNoise) and g["denoiser_scaling"] == "VScalingWithEDMcNoise"
+    d, v = P.DEFAULTS, VaeConfig()
+    assert d["seed"] == g["seed_everything"] and d["num_steps"] == sm["num_steps"] and d["num_frames_per_chunk"] == sm["num_frames"]
+    assert d["num_conditional_frames"] == g["inference"]["num_conditional_frames"]
+    sig = inspect.signature(StreamingSVD._autoregressive_generation)
+    assert sig.parameters["anchor_index"].default == int(g["inference"]["anchor_frames"])
+    assert inspect.signature(StreamingSVD.__init__).parameters["scale_factor"].default == g["scale_factor"]
+    assert (v.ch, list(v.ch_mult), v.num_res_blocks, v.z_channels, v.out_ch) == tuple(g["decoder"][k] for k in ("ch", "ch_mult", "num_res_blocks", "z_channels", "out_ch"))
