@@ -549,6 +549,10 @@ def test_enhance_video_structure_matches_reference_process(monkeypatch):
             for k in ("image", "video", "chunk_size", "overlap_size", "num_frames", "strength", "num_inference_steps", "guidance_scale"):
                 assert got[k] == want[k], (name, k)
             assert got["n_conds"] == got["n_windows"] == len(want["image"])
+            d = pipeline.DEFAULTS            # what the reference passes besides (i2v_enhance_interface.py:87-88, 99-133)
+            assert (want["prompt"], want["negative_prompt"]) == (d["prompt"], d["negative_prompt"])
+            assert (want["height"], want["width"], want["decode_chunk_size"]) == (d["enhance_height"], d["enhance_width"], 1)
+            assert "target_fps" not in want and d["enhance_target_fps"] == 38          # not passed: the fork's __call__ default applies
         assert [crc(f) for f in out] == ref["out"], name
 
 
