@@ -5,14 +5,19 @@ import torch
 import torch.nn.functional as F
 
 
-def text_tower(sd, input_ids, heads, prefix="text_model."):
+def text_tower(sd, input_ids, heads, prefix="text_model.", clip_skip=None):
+    """clip_skip=k: hidden_states[-(k + 1)] (the last k encoder layers skipped) through final_layer_norm, as encode_prompt does for
+    clip_skip is not None (pipeline_i2vgen_xl.py:246-260); the fork's __call__ default is clip_skip=1 (:645)."""
     g = lambda k: sd[prefix + k]
     B, L = input_ids.shape
     x = g("embeddings.token_embedding.weight")[input_ids] + g("embeddings.position_embedding.weight")[:L][None]
     W = x.shape[-1]
     mask = torch.triu(torch.full((L, L), float("-inf")), diagonal=1)
+    n_layers = 0
+    while f"{prefix}encoder.layers.{n_layers}.layer_norm1.weight" in sd:
+        n_layers += 1
     i = 0
-    while f"{prefix}encoder.layers.{i}.layer_norm1.weight" in sd:
+    while i < n_layers - (clip_skip or 0):
         b = f"encoder.layers.{i}."
         h = F.layer_norm(x, (W,), g(b + "layer_norm1.weight"), g(b + "layer_norm1.bias"), 1e-5)
         q, k, v = (F.linear(h, g(b + f"self_attn.{n}_proj.weight"), g(b + f"self_attn.{n}_proj.bias")) for n in "qkv")

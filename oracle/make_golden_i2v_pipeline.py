@@ -70,10 +70,45 @@ def main():
     print("[i2v call] reference-vs-oracle max abs err:", {k: f"{v:.2e}" for k, v in errs.items()}, "| timesteps", trace["timesteps"],
           "| fps", trace["fps"].tolist(), f"| final std {ref.std():.3f}")
     assert max(errs.values()) <= 1e-4, errs
+    # encode_prompt (:169-347) with the fork's default clip_skip = 1, on a real (tiny, random) transformers CLIPTextModel: the oracle's
+    # text tower with clip_skip must reproduce it; the defaults of __call__ that i2v_enhance_interface.py relies on are recorded.
+    import inspect
+    import types
+    import transformers as tr
+    from oracle.clip_text_oracle import text_tower
+    torch.manual_seed(0)
+    tcfg = tr.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+                             max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5, eos_token_id=2, bos_token_id=0, pad_token_id=1)
+    hf = tr.CLIPTextModel(tcfg).eval()
+    for p_ in hf.parameters():
+        p_.normal_(0, 0.05)
+    if not hasattr(hf, "text_model"):
+        object.__setattr__(hf, "text_model", hf)                     # transformers 4.40 layout (the reference's pin)
+    ids = {"P": torch.randint(3, 1000, (1, 77)), "N": torch.randint(3, 1000, (1, 77))}
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, text, **kw):
+            t = text[0] if isinstance(text, list) else text
+            return types.SimpleNamespace(input_ids=ids[t], attention_mask=torch.ones_like(ids[t]))
+
+        def batch_decode(self, x):
+            return [""]
+    defaults = {k: v.default for k, v in inspect.signature(mod.I2VGenXLPipeline.__call__).parameters.items()
+                if isinstance(v.default, (int, float, str, bool, type(None))) and v.default is not inspect.Parameter.empty}
+    bare = types.SimpleNamespace(tokenizer=Tok(), text_encoder=hf, unet=None, do_classifier_free_guidance=True)
+    pe, ne = mod.I2VGenXLPipeline.encode_prompt(bare, "P", "cpu", 1, "N", clip_skip=defaults["clip_skip"])
+    tsd = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in hf.state_dict().items() if "position_ids" not in k}
+    e = max((pe - text_tower(tsd, ids["P"], 2, clip_skip=defaults["clip_skip"])).abs().max().item(),
+            (ne - text_tower(tsd, ids["N"], 2, clip_skip=defaults["clip_skip"])).abs().max().item())
+    print(f"[i2v call] encode_prompt(clip_skip={defaults['clip_skip']}) reference-vs-oracle {e:.2e}; __call__ defaults: target_fps {defaults['target_fps']}, "
+          f"clip_skip {defaults['clip_skip']}, decode_chunk_size {defaults['decode_chunk_size']}")
+    assert e <= 1e-5
     out = os.path.join(ROOT, "tests", "golden", "i2v_call_tiny.pt")
     torch.save(dict(final=ref.clone(), init_latents=trace["init_latents"], clean=trace["clean"], noise=trace["noise"], timesteps=trace["timesteps"], fps=calls[0]["fps"],
                     image_latents=[calls[i]["image_latents"] for i in range(2)], image_embeddings=[calls[i]["image_embeddings"] for i in range(2)],
-                    text=calls[0]["text"], vae_encode_calls=pipe.vae.encode_calls), out)
+                    text=calls[0]["text"], vae_encode_calls=pipe.vae.encode_calls, call_defaults=defaults), out)
     print("wrote", out, os.path.getsize(out), "bytes")
 
 

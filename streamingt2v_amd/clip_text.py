@@ -62,8 +62,9 @@ class CLIPTextTower:
         self.device = dev
         return self
 
-    def forward(self, input_ids):
-        """input_ids int64 [B, L <= 77] -> last_hidden_state fp32 [B, L, width]."""
+    def forward(self, input_ids, clip_skip=None):
+        """input_ids int64 [B, L <= 77] -> last_hidden_state fp32 [B, L, width]; with clip_skip = k the last k encoder layers are skipped
+        and the final LayerNorm is applied to hidden_states[-(k + 1)] (encode_prompt, pipeline_i2vgen_xl.py:246-260)."""
         c, dev = self.cfg, self.device
         B, L = input_ids.shape
         T = (L + 3) // 4 * 4
@@ -80,7 +81,7 @@ class CLIPTextTower:
         s = torch.empty((T, T), dtype=torch.float32, device=dev)
         pm = torch.zeros((T, tld), dtype=x.dtype, device=dev)
         o = torch.empty((B * T, W), dtype=x.dtype, device=dev)
-        for blk in self.blocks:
+        for blk in self.blocks[: len(self.blocks) - (clip_skip or 0)]:
             n1 = ops.layernorm(x, *blk["ln1"])
             qk = ops.gemm(n1, blk["wqk"], bias=blk["bqk"])
             ops.gemm(n1, blk["wv"], bias=blk["bv"], trans_out=dict(tok_per_frame=T, tokens_ld=tld, out=vt))

@@ -49,10 +49,12 @@ class EnhanceCodec:
         self.prompt_embeds = self.negative_prompt_embeds = None
 
     # ---- text ---------------------------------------------------------------------------------------------------------------
-    def set_prompts_from_ids(self, prompt_ids, negative_ids):
-        """token ids [1, 77] of the prompt / negative prompt (CLIPTokenizer output, padding='max_length'; encode_prompt :250-347)."""
-        self.prompt_embeds = self.text_tower(prompt_ids)
-        self.negative_prompt_embeds = self.text_tower(negative_ids)
+    def set_prompts_from_ids(self, prompt_ids, negative_ids, clip_skip=1):
+        """token ids [1, 77] of the prompt / negative prompt (CLIPTokenizer output, padding='max_length'; encode_prompt :250-347).
+        clip_skip = 1 is the default of the fork's __call__ (:645; i2v_enhance_interface.py does not pass it): the LAST encoder layer is
+        skipped and the final LayerNorm applied to the layer before it."""
+        self.prompt_embeds = self.text_tower(prompt_ids, clip_skip=clip_skip)
+        self.negative_prompt_embeds = self.text_tower(negative_ids, clip_skip=clip_skip)
 
     def set_prompts(self, prompt, negative_prompt, tokenizer):
         """prompt strings through `clip_tokenizer.CLIPBPETokenizer` (or any tokenizer with the transformers call signature)."""

@@ -391,3 +391,6 @@ def test_clip_text_tower_vs_oracle(elem):
     with torch.no_grad():
         ref = text_tower(sd, ids, cfg.heads)
     report("CLIP text tower", out.reshape(2, 77, 256), ref)
+    with torch.no_grad():                              # clip_skip = 1: the enhancer's prompt path (pipeline_i2vgen_xl.py:246-260, default :645)
+        ref1 = text_tower(sd, ids, cfg.heads, clip_skip=1)
+    report("CLIP text tower, clip_skip 1", tower(ids, clip_skip=1).reshape(2, 77, 256), ref1)

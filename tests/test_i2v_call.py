@@ -77,6 +77,18 @@ def test_product_host_side_reproduces_reference_unet_inputs():
     assert (sched.add_noise(lat, noise, g["timesteps"][0]) - g["init_latents"]).abs().max() <= 2e-6
 
 
+def test_product_defaults_match_reference_call_defaults():
+    """Arguments i2v_enhance_interface.py does NOT pass take the defaults of the fork's __call__ (recorded in the golden): the product must
+    use the same ones -- fps conditioning 38, clip_skip 1 (last text-encoder layer skipped), frame-by-frame decoding."""
+    import inspect
+    from streamingt2v_amd.enhance_codec import EnhanceCodec
+    from streamingt2v_amd.pipeline import DEFAULTS
+    d = torch.load(GOLD)["call_defaults"]
+    assert (d["target_fps"], d["clip_skip"], d["decode_chunk_size"], d["eta"]) == (38, 1, 1, 0.0)
+    assert inspect.signature(EnhanceCodec.__init__).parameters["target_fps"].default == d["target_fps"] == DEFAULTS["enhance_target_fps"]
+    assert inspect.signature(EnhanceCodec.set_prompts_from_ids).parameters["clip_skip"].default == d["clip_skip"]
+
+
 def test_encode_video_chunks_like_torch_chunk():
     """prepare_video_latents :585-597: more than 16 frames are encoded as torch.chunk(video, F // 16) -- ceil-sized chunks, last one short."""
     from streamingt2v_amd.enhance_codec import EnhanceCodec

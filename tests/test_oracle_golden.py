@@ -179,4 +179,9 @@ def test_clip_text_oracle_matches_hf():
         # transformers 4.40 (the reference's pin, and the published checkpoint) prefixes the keys with "text_model."; 5.x does not
         sd = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in hf.state_dict().items() if "position_ids" not in k}
         out = text_tower(sd, ids, 2)
+        # clip_skip = 1 (the fork's __call__ default): hidden_states[-2] through the final LayerNorm (pipeline_i2vgen_xl.py:246-260)
+        hs = hf(input_ids=ids, output_hidden_states=True).hidden_states
+        ln = (hf.text_model if hasattr(hf, "text_model") else hf).final_layer_norm
+        assert (ln(hs[-2]) - text_tower(sd, ids, 2, clip_skip=1)).abs().max().item() <= 2e-5
+        assert (ln(hs[-1]) - out).abs().max().item() <= 2e-5 and (ln(hs[-2]) - out).abs().max().item() > 1e-3
     assert (ref - out).abs().max().item() <= 2e-5
