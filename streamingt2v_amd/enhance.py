@@ -31,8 +31,16 @@ class DDIMSchedule:
     fp64 table math; the per-element update is the HIP kernel.  (diffusers is not vendored: parity unpinned, see oracle header.)"""
 
     def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, prediction_type="v_prediction",
-                 rescale_betas_zero_snr=True, set_alpha_to_one=False):
-        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+                 rescale_betas_zero_snr=True, set_alpha_to_one=False, beta_schedule="scaled_linear", timestep_spacing="leading"):
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train, dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"DDIM beta_schedule {beta_schedule!r}")
+        if prediction_type not in ("v_prediction", "epsilon") or timestep_spacing not in ("leading", "trailing", "linspace"):
+            raise NotImplementedError(f"DDIM prediction_type {prediction_type!r} / timestep_spacing {timestep_spacing!r}")
+        self.spacing = timestep_spacing
         if rescale_betas_zero_snr:
             ac = torch.cumprod(1.0 - betas, 0).sqrt()
             a0, aT = ac[0].clone(), ac[-1].clone()
@@ -43,9 +51,28 @@ class DDIMSchedule:
         self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(self.alphas_cumprod[0])
         self.num_train, self.offset, self.v_prediction = num_train, steps_offset, prediction_type == "v_prediction"
 
+    @classmethod
+    def from_config(cls, cfg):
+        """scheduler/scheduler_config.json of a diffusers pipeline folder (what DDIMScheduler.from_pretrained reads).  Options that would
+        change the update rule and are not implemented (sample clipping, thresholding) are refused instead of ignored."""
+        if cfg.get("clip_sample", False) or cfg.get("thresholding", False):
+            raise NotImplementedError("DDIM clip_sample / thresholding are not implemented (ali-vilab/i2vgen-xl sets both to false)")
+        return cls(num_train=cfg.get("num_train_timesteps", 1000), beta_start=cfg.get("beta_start", 0.0001), beta_end=cfg.get("beta_end", 0.02),
+                   steps_offset=cfg.get("steps_offset", 0), prediction_type=cfg.get("prediction_type", "epsilon"),
+                   rescale_betas_zero_snr=cfg.get("rescale_betas_zero_snr", False), set_alpha_to_one=cfg.get("set_alpha_to_one", True),
+                   beta_schedule=cfg.get("beta_schedule", "linear"), timestep_spacing=cfg.get("timestep_spacing", "leading"))
+
     def set_timesteps(self, n):
-        self.n = n
-        self.timesteps = [int(i * (self.num_train // n)) + self.offset for i in range(n)][::-1]
+        """diffusers DDIMScheduler.set_timesteps for the three spacings."""
+        import numpy as np
+        self.n, T = n, self.num_train
+        if self.spacing == "leading":
+            ts = (np.arange(0, n) * (T // n)).round()[::-1].astype(np.int64) + self.offset
+        elif self.spacing == "trailing":
+            ts = np.round(np.arange(T, 0, -T / n)).astype(np.int64) - 1
+        else:
+            ts = np.linspace(0, T - 1, n).round()[::-1].astype(np.int64)
+        self.timesteps = [int(t) for t in ts]
         return self.timesteps
 
     def get_timesteps(self, n, strength):

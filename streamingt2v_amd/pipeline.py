@@ -106,6 +106,11 @@ def load_enhancer(folder, device="cuda", variant="fp16", generator=None):
     if gen is None and str(device).startswith("cuda"):
         gen = torch.Generator(device=device).manual_seed(DEFAULTS["enhance_generator_seed"])       # torch.manual_seed(8888), interface :64
     codec = EnhanceCodec(vae, tower, text, generator=gen, device=device)
+    sched_cfg = os.path.join(folder, "scheduler", "scheduler_config.json")
+    if os.path.exists(sched_cfg):                                   # the checkpoint's own DDIM configuration, not the recalled defaults
+        from .enhance import DDIMSchedule
+        with open(sched_cfg) as f:
+            codec.scheduler = DDIMSchedule.from_config(json.load(f))
     tok_dir = os.path.join(folder, "tokenizer")
     if os.path.exists(os.path.join(tok_dir, "vocab.json")):        # the pipeline's CLIPTokenizer files: prompts of i2v_enhance_interface.py:99-100
         from .clip_tokenizer import CLIPBPETokenizer
@@ -236,8 +241,8 @@ class StreamingPipeline:
                                       "AutoencoderKL encode/decode of the I2VGen-XL pipeline; SURVEY.md 8f N4)")
         from .enhance import I2VEnhancer
         c, codec = self.cfg, self.enhance_codec
-        enh = I2VEnhancer(self.enhancer_unet, guidance_scale=c["enhance_guidance_scale"], num_inference_steps=c["enhance_steps"],
-                          strength=strength)
+        enh = I2VEnhancer(self.enhancer_unet, getattr(codec, "scheduler", None), guidance_scale=c["enhance_guidance_scale"],
+                          num_inference_steps=c["enhance_steps"], strength=strength)
         rng = random.Random(c["seed"])
         video = list(video)
         images = [resize_key_image(image, getattr(codec, "w", c["enhance_width"]), getattr(codec, "h", c["enhance_height"]))]

@@ -678,3 +678,22 @@ def test_defaults_match_reference_config_values():
     assert sig.parameters["anchor_index"].default == int(g["inference"]["anchor_frames"])
     assert inspect.signature(StreamingSVD.__init__).parameters["scale_factor"].default == g["scale_factor"]
     assert (v.ch, list(v.ch_mult), v.num_res_blocks, v.z_channels, v.out_ch) == tuple(g["decoder"][k] for k in ("ch", "ch_mult", "num_res_blocks", "z_channels", "out_ch"))
+
+
+def test_ddim_schedule_from_config_and_spacings():
+    """enhance.DDIMSchedule.from_config (scheduler/scheduler_config.json of the checkpoint folder): the i2vgen-xl values reproduce the default
+    schedule; the three diffusers timestep spacings; update-rule options that are not implemented are refused."""
+    import pytest
+    from streamingt2v_amd.enhance import DDIMSchedule
+    i2v = dict(_class_name="DDIMScheduler", beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, num_train_timesteps=1000,
+               prediction_type="v_prediction", rescale_betas_zero_snr=True, set_alpha_to_one=False, steps_offset=1, timestep_spacing="leading", thresholding=False)
+    a, b = DDIMSchedule.from_config(i2v), DDIMSchedule()
+    assert torch.equal(a.alphas_cumprod, b.alphas_cumprod) and a.set_timesteps(30) == b.set_timesteps(30) and a.alphas(201) == b.alphas(201)
+    assert b.set_timesteps(10) == [901, 801, 701, 601, 501, 401, 301, 201, 101, 1]
+    assert DDIMSchedule.from_config(dict(i2v, timestep_spacing="trailing", steps_offset=0)).set_timesteps(10) == [999, 899, 799, 699, 599, 499, 399, 299, 199, 99]
+    assert DDIMSchedule.from_config(dict(i2v, timestep_spacing="linspace", steps_offset=0)).set_timesteps(4) == [999, 666, 333, 0]
+    lin = DDIMSchedule.from_config(dict(beta_schedule="linear", beta_start=0.0001, beta_end=0.02))
+    assert not lin.v_prediction and abs(float(lin.alphas_cumprod[-1]) - 4.0358e-05) < 1e-7 and lin.final_alpha_cumprod == 1.0
+    for bad in (dict(i2v, clip_sample=True), dict(i2v, thresholding=True), dict(i2v, beta_schedule="squaredcos_cap_v2"), dict(i2v, prediction_type="sample")):
+        with pytest.raises(NotImplementedError):
+            DDIMSchedule.from_config(bad)
