@@ -73,3 +73,42 @@ def test_header_is_plain_c(tmp_path):
     for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only"], ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++"]):
         r = subprocess.run(cmd + ["-I", inc, str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_signatures_match_header_prototypes():
+    """Every prototype of include/svdhip.h against the argtypes the binding declares: same arity, and per parameter the same class
+    (pointer / stream -> c_void_p, int32_t -> c_int32, int64_t -> c_int64, float -> c_float, int* -> POINTER(c_int)).  A mismatch here
+    would not crash -- it would silently pass garbage to a kernel."""
+    from streamingt2v_amd.lib import lib
+    txt = open(os.path.join(ROOT, "include", "svdhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|const char\s*\*)\s*(svd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S)
+    assert len(protos) >= 30
+    checked = 0
+    for name, params in protos:
+        fn = getattr(lib, name)
+        params = " ".join(params.split())
+        plist = [] if params in ("void", "") else [p.strip() for p in params.split(",")]
+        if fn.argtypes is None:
+            assert not plist, f"{name}: no argtypes declared for {len(plist)} parameters"
+            continue
+        assert len(fn.argtypes) == len(plist), f"{name}: header has {len(plist)} parameters, binding {len(fn.argtypes)}"
+        for i, (p, t) in enumerate(zip(plist, fn.argtypes)):
+            if "*" in p:
+                want = "pointer"
+            elif p.startswith("svd_stream_t"):
+                want = "pointer"
+            elif p.startswith("int64_t"):
+                want = ctypes.c_int64
+            elif p.startswith("int32_t") or p.startswith("int "):
+                want = ctypes.c_int32
+            elif p.startswith("float"):
+                want = ctypes.c_float
+            else:
+                raise AssertionError(f"{name}: unhandled parameter type in '{p}'")
+            if want == "pointer":
+                assert t is ctypes.c_void_p or hasattr(t, "contents") or issubclass(t, ctypes._Pointer), f"{name} arg {i} ('{p}'): {t}"
+            else:
+                assert t is want or (want is ctypes.c_int32 and t is ctypes.c_int), f"{name} arg {i} ('{p}'): binding {t}, header wants {want}"
+            checked += 1
+    assert checked >= 250
