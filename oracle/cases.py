@@ -233,3 +233,16 @@ def tiny_svd_cond_inputs():
     g = _gen(1003)
     c = TINY_SVD_COND
     return dict(frame=torch.rand(3, c["H"], c["W"], generator=g) * 2 - 1, ctrl_frames=torch.rand(1, c["Tc"], 3, c["H"], c["W"], generator=g) * 2 - 1)
+
+
+# ---- the shipped architecture on a small latent (oracle/make_golden_fullarch.py, tools/fullarch_parity.py) ----
+FULLARCH_CASE = dict(T=3, Tc=2, h=16, w=16, seed_unet=33, seed_cn=34)
+
+
+def fullarch_inputs():
+    g = _gen(5150)
+    c = FULLARCH_CASE
+    F, h, w = 2 * c["T"], c["h"], c["w"]
+    return dict(x=torch.randn(F, 4, h, w, generator=g), t=torch.randn(F, generator=g) * 0.5, concat=torch.randn(F, 4, h, w, generator=g) * 0.5,
+                crossattn=torch.randn(F, 1, 1024, generator=g), vector=torch.randn(F, 768, generator=g) * 0.5,
+                ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
