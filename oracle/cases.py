@@ -246,3 +246,16 @@ def fullarch_inputs():
     return dict(x=torch.randn(F, 4, h, w, generator=g), t=torch.randn(F, generator=g) * 0.5, concat=torch.randn(F, 4, h, w, generator=g) * 0.5,
                 crossattn=torch.randn(F, 1, 1024, generator=g), vector=torch.randn(F, 768, generator=g) * 0.5,
                 ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
+
+
+# ---- the enhancer UNet at its shipped configuration on a small latent (oracle/make_golden_i2v_fullarch.py) ----
+I2V_FULLARCH_CASE = dict(F=4, h=9, w=16, text_tokens=77, seed=6)
+
+
+def i2v_fullarch_inputs():
+    g = _gen(778)
+    c = I2V_FULLARCH_CASE
+    B, Fr, h, w, cd = 2, c["F"], c["h"], c["w"], 1024
+    return dict(sample=torch.randn(B, 4, Fr, h, w, generator=g), t=torch.tensor(481), fps=torch.tensor([38, 38]),
+                image_latents=torch.randn(B, 4, Fr, h, w, generator=g) * 0.7, image_embeddings=torch.randn(B, cd, generator=g),
+                text=torch.randn(B, c["text_tokens"], cd, generator=g))

@@ -2,7 +2,10 @@
 channels, attention at every level, 2 res blocks) on a small latent against the REFERENCE's own output, tests/golden/wrapper_fullarch.pt
 (oracle/make_golden_fullarch.py ran the unmodified reference modules on CPU; the oracle agrees with them to 4.9e-6 there).
 
-    python tools/fullarch_parity.py [--dtype bf16|fp16|both]
+    python tools/fullarch_parity.py [--dtype bf16|fp16|both] [--which svd|i2v|both]
+
+`--which i2v`: the enhancer's I2VGenXLUNet at its shipped configuration (1.42 B parameters) on a 9x16 latent against
+tests/golden/i2v_fullarch.pt (oracle/make_golden_i2v_fullarch.py: the unmodified vendored module; oracle agreement 3.2e-6).
 
 The committed GPU tests compare against the reference at the tiny configuration (2 levels, 1 res block) and check the full size
 structurally; this closes the gap between the two.  Written after the round's GPU budget was spent: run it first next round, then promote
@@ -21,6 +24,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="both")
+    ap.add_argument("--which", default="both")
     a = ap.parse_args()
     from oracle.cases import FULLARCH_CASE as c, fullarch_inputs
     from streamingt2v_amd import ops
@@ -40,6 +44,27 @@ def main():
         corr = torch.corrcoef(torch.stack([out.flatten(), ref.flatten()]))[0, 1].item()
         print(f"[{name}] per-frame L2 abs max {e.max():.3e} mean {e.mean():.3e} | rel max {(e / r).max():.3e} | corr {corr:.6f}")
 
+    if a.which in ("both", "i2v"):
+        from oracle.cases import I2V_FULLARCH_CASE as ci, i2v_fullarch_inputs
+        from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+        g2 = torch.load(os.path.join(ROOT, "tests", "golden", "i2v_fullarch.pt"))["out"]
+        sd_e = init_by_name(I2VGenXLUNet(I2VConfig()).spec(), seed=ci["seed"])
+        ei = i2v_fullarch_inputs()
+        fr = lambda x: x.permute(0, 2, 1, 3, 4).reshape(-1, *x.shape[1:2], *x.shape[3:])
+        for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+            if a.dtype not in ("both", name):
+                continue
+            ops.set_element_dtype(dt)
+            eu = I2VGenXLUNet(I2VConfig())
+            eu.load_state_dict(sd_e, device="cuda")
+            out = eu(ei["sample"], ei["t"], fps=ei["fps"], image_latents=ei["image_latents"], image_embeddings=ei["image_embeddings"],
+                     encoder_hidden_states=ei["text"])[0]
+            report(f"full-architecture I2VGenXLUNet vs vendored reference, {name}", fr(out), fr(g2))
+            del eu
+            torch.cuda.empty_cache()
+        del sd_e
+    if a.which not in ("both", "svd"):
+        return
     for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
         if a.dtype not in ("both", name):
             continue
