@@ -259,3 +259,12 @@ def i2v_fullarch_inputs():
     return dict(sample=torch.randn(B, 4, Fr, h, w, generator=g), t=torch.tensor(481), fps=torch.tensor([38, 38]),
                 image_latents=torch.randn(B, 4, Fr, h, w, generator=g) * 0.7, image_embeddings=torch.randn(B, cd, generator=g),
                 text=torch.randn(B, c["text_tokens"], cd, generator=g))
+
+
+# ---- shipped-architecture cases of the smaller networks (oracle/make_golden_fullarch_small.py) ----
+def fullarch_small_inputs():
+    g = _gen(3131)
+    low = torch.rand(1, 6, 64 // 8 + 2, 96 // 8 + 2, generator=g)
+    pair = torch.nn.functional.interpolate(low, scale_factor=8, mode="bicubic", align_corners=False).clamp(0, 1)[:, :, 4:4 + 64, 7:7 + 96].contiguous()
+    return dict(z=torch.randn(3, 4, 8, 8, generator=g), x_enc=torch.rand(1, 3, 64, 64, generator=g) * 2 - 1,
+                img0=pair[:, :3].contiguous(), img1=pair[:, 3:].contiguous())

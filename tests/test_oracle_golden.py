@@ -185,3 +185,24 @@ def test_clip_text_oracle_matches_hf():
         assert (ln(hs[-2]) - text_tower(sd, ids, 2, clip_skip=1)).abs().max().item() <= 2e-5
         assert (ln(hs[-1]) - out).abs().max().item() <= 2e-5 and (ln(hs[-2]) - out).abs().max().item() > 1e-3
     assert (ref - out).abs().max().item() <= 2e-5
+
+
+def test_oracles_match_reference_at_shipped_sizes():
+    """Temporal VideoDecoder and sgm Encoder at the shipped size (ch 128, mult 1-2-4-4, 2 res blocks) and EMA-VFI at F = 32: the oracles
+    against the outputs of the UNMODIFIED reference modules (tests/golden/*_fullarch.pt, oracle/make_golden_fullarch_small.py)."""
+    import os
+    from oracle import svd_oracle as O, vfi_oracle as OV
+    from oracle.cases import fullarch_small_inputs, vfi_weights
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import Encoder, VideoDecoder
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    inp = fullarch_small_inputs()
+    with torch.no_grad():
+        sd = init_by_name(VideoDecoder().spec(), seed=35)
+        assert (O.video_decoder(sd, O.VaeCfg(), inp["z"], 3) - torch.load(os.path.join(gd, "vae_fullarch.pt"))["out"]).abs().max() <= 5e-4
+        sd = init_by_name(Encoder().spec(), seed=36)
+        assert (O.vae_encoder(sd, O.VaeCfg(), inp["x_enc"]) - torch.load(os.path.join(gd, "vae_enc_fullarch.pt"))["out"]).abs().max() <= 5e-4
+        sd = vfi_weights(EMAVFI(VFIConfig()).spec(), seed=12)
+        out = OV.inference_fast_tta(sd, OV.vfi_config(32, (2, 2, 2, 4, 4)), inp["img0"], inp["img1"])
+        assert (out - torch.load(os.path.join(gd, "vfi_fullarch.pt"))["tta"]).abs().max() <= 1e-5

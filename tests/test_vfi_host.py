@@ -156,26 +156,27 @@ def test_load_vfi_from_reference_style_checkpoint(tmp_path):
 
 def test_vfi_host_logic_at_shipped_width(monkeypatch):
     """The shipped configuration (F = 32: 32 .. 512 channels, 8 / 16 heads, channel counts such as 81, 134 and 224 that need padding) on a
-    small frame pair: EMAVFI's host logic with the fp32 stand-in launchers against the oracle."""
-    import time
+    small frame pair: EMAVFI's host logic with the fp32 stand-in launchers against the oracle, and its fast-TTA result against the output
+    of the UNMODIFIED vendored network at F = 32 (tests/golden/vfi_fullarch.pt, oracle/make_golden_fullarch_small.py)."""
     import vfi_shim
+    from oracle.cases import fullarch_small_inputs
     from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
     torch.set_grad_enabled(False)
     vfi_shim.install(monkeypatch)
     model = EMAVFI(VFIConfig())
     sd = vfi_weights(model.spec(), seed=12)
     model.load_state_dict(sd, device="cpu")
-    H, W = 64, 96
-    g = torch.Generator().manual_seed(5)
-    low = torch.rand(1, 6, H // 8 + 2, W // 8 + 2, generator=g)
-    x = torch.nn.functional.interpolate(low, scale_factor=8, mode="bicubic", align_corners=False).clamp(0, 1)[:, :, 4:4 + H, 7:7 + W].contiguous()
+    inp = fullarch_small_inputs()
+    H, W = inp["img0"].shape[2:]
+    x = torch.cat((inp["img0"], inp["img1"]), 1)
     cl = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
-    t0 = time.time()
     r = model.net_forward(cl(x[:, :3]), cl(x[:, 3:6]), 1, H, W, want=True)
     o = O.net_forward(sd, O.vfi_config(32, (2, 2, 2, 4, 4)), x)
-    print(f"[vfi F=32 host logic] {time.time() - t0:.1f} s; |flow| max {o['flow'].abs().max():.2f}")
     for lvl in range(5):
         t, C, h, w = r["af"][lvl]
         assert C == 32 * 2 ** lvl and (t[:, :C] - cl(o["af"][lvl])).abs().max() <= 5e-4, f"af{lvl}"
     assert (r["fm"][:, :4] - cl(o["flow"])).abs().max() <= 2e-3
     assert (r["pred"] - cl(o["pred"])).abs().max() <= 5e-4
+    mid = model.inference(inp["img0"][0].permute(1, 2, 0).contiguous(), inp["img1"][0].permute(1, 2, 0).contiguous())
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "vfi_fullarch.pt"))["tta"]
+    assert (mid - gold[0].permute(1, 2, 0)).abs().max() <= 5e-4
