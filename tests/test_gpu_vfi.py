@@ -205,3 +205,20 @@ def test_vfi_network_other_sizes(ops, H, W, B):
         _rel(f"af{lvl} {H}x{W}", t[:, :C], cl(o["af"][lvl]), 3e-2)
     close(f"flow [px] {H}x{W}", r["fm"][:, :4], cl(o["flow"]), 0.2, 0.0)
     close(f"pred {H}x{W}", r["pred"], cl(o["pred"]), 2.5e-2, 0.0)
+
+
+def test_vfi_shipped_width_vs_reference_golden(ops):
+    """EMA-VFI at the SHIPPED width (F = 32, 65.7 M parameters) on a 64x96 frame pair against the fast-TTA output of the UNMODIFIED vendored
+    network (tests/golden/vfi_fullarch.pt, oracle/make_golden_fullarch_small.py).  16-bit emulation on CPU predicts 2.5e-3 (bf16) /
+    3.2e-4 (fp16) max abs error and at most 1 uint8 level."""
+    from oracle.cases import fullarch_small_inputs, vfi_weights
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    torch.set_grad_enabled(False)
+    model = EMAVFI(VFIConfig())
+    model.load_state_dict(vfi_weights(model.spec(), seed=12), device=DEV)
+    inp = fullarch_small_inputs()
+    gold = torch.load(os.path.join(os.path.dirname(GOLD), "vfi_fullarch.pt"))["tta"][0].permute(1, 2, 0)
+    mid, u8 = model.inference(inp["img0"][0].permute(1, 2, 0).contiguous().to(DEV), inp["img1"][0].permute(1, 2, 0).contiguous().to(DEV), want_uint8=True)
+    close("EMA-VFI F=32 fast-TTA vs vendored network", mid, gold, 2e-2, 0.0)
+    d = (u8.cpu().int() - (gold * 255.0).to(torch.uint8).int()).abs()
+    assert d.max().item() <= (4 if ELEM == torch.bfloat16 else 2)
