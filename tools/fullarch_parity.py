@@ -2,7 +2,11 @@
 channels, attention at every level, 2 res blocks) on a small latent against the REFERENCE's own output, tests/golden/wrapper_fullarch.pt
 (oracle/make_golden_fullarch.py ran the unmodified reference modules on CPU; the oracle agrees with them to 4.9e-6 there).
 
-    python tools/fullarch_parity.py [--dtype bf16|fp16|both] [--which svd|i2v|both]
+    python tools/fullarch_parity.py [--dtype bf16|fp16|both] [--which svd|i2v|vae|both]
+
+`--which vae` (also part of `both`): temporal VideoDecoder and sgm Encoder at the shipped size against tests/golden/vae_fullarch.pt /
+vae_enc_fullarch.pt (oracle/make_golden_fullarch_small.py).  The encoder's mid attention sees only 64 tokens here (8x8 latent) and the
+AEAttnBlock path wants pixels % 64 == 0 -- satisfied, but smaller than any shape tested so far.
 
 `--which i2v`: the enhancer's I2VGenXLUNet at its shipped configuration (1.42 B parameters) on a 9x16 latent against
 tests/golden/i2v_fullarch.pt (oracle/make_golden_i2v_fullarch.py: the unmodified vendored module; oracle agreement 3.2e-6).
@@ -44,6 +48,23 @@ def main():
         corr = torch.corrcoef(torch.stack([out.flatten(), ref.flatten()]))[0, 1].item()
         print(f"[{name}] per-frame L2 abs max {e.max():.3e} mean {e.mean():.3e} | rel max {(e / r).max():.3e} | corr {corr:.6f}")
 
+    if a.which in ("both", "vae"):
+        from oracle.cases import fullarch_small_inputs
+        from streamingt2v_amd.temporal_ae import Encoder, VideoDecoder
+        si = fullarch_small_inputs()
+        gdir = os.path.join(ROOT, "tests", "golden")
+        for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+            if a.dtype not in ("both", name):
+                continue
+            ops.set_element_dtype(dt)
+            dec = VideoDecoder()
+            dec.load_state_dict(init_by_name(dec.spec(), seed=35), device="cuda")
+            report(f"shipped-size VideoDecoder vs reference, {name}", dec.forward(si["z"].cuda(), timesteps=3), torch.load(os.path.join(gdir, "vae_fullarch.pt"))["out"])
+            enc = Encoder()
+            enc.load_state_dict(init_by_name(enc.spec(), seed=36), device="cuda")
+            report(f"shipped-size VAE Encoder vs reference, {name}", enc(si["x_enc"].cuda()), torch.load(os.path.join(gdir, "vae_enc_fullarch.pt"))["out"])
+            del dec, enc
+            torch.cuda.empty_cache()
     if a.which in ("both", "i2v"):
         from oracle.cases import I2V_FULLARCH_CASE as ci, i2v_fullarch_inputs
         from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
