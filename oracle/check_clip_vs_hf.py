@@ -45,6 +45,19 @@ def main():
     e = (ref - out).abs().max().item()
     print(f"[clip oracle vs HF CLIPVisionModelWithProjection] max abs err {e:.3e} (|ref| max {ref.abs().max():.3f})")
     assert e <= 2e-5, e
+    if "--full" in sys.argv:       # ViT-H/14 as shipped: 32 layers x 1280, 16 heads of 80, 257 tokens, projection 1024 (632 M parameters)
+        cfg = CLIPVisionConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, image_size=224, patch_size=14,
+                               projection_dim=1024, hidden_act="gelu", layer_norm_eps=1e-5)
+        hf = CLIPVisionModelWithProjection(cfg).eval()
+        with torch.no_grad():
+            for p in hf.parameters():
+                p.normal_(0, 0.02)
+            img = torch.randn(1, 3, 224, 224)
+            ref = hf(pixel_values=img).image_embeds
+            out = vision_tower(hf_to_openclip(hf.state_dict(), 32), img, 16, 14)
+        e = (ref - out).abs().max().item()
+        print(f"[clip oracle vs HF, ViT-H/14 size] max abs err {e:.3e} (|ref| max {ref.abs().max():.3f}, rel {e / ref.abs().max().item():.2e})")
+        assert e <= 1e-4 * max(1.0, ref.abs().max().item()), e
 
 
 if __name__ == "__main__":
