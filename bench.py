@@ -1,21 +1,30 @@
 #!/usr/bin/env python
-"""bench.py -- generated frames/sec of the StreamingSVD denoising hot path on MI355X (BASELINE.json metric).
+"""bench.py -- generated frames/sec of the StreamingSVD hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|ar_chunk|c3|enhance|vfi] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stage1|c2|ar_chunk|c3|enhance|vfi] [--dtype fp16|bf16]
 
-One "step" = one pass of the hot path over one batch of synthetic input = ONE CHUNK: all Euler-EDM steps of the
-UNet (CFG batch 2 x 25 frames at 576x1024 -> latent 72x128) + the temporal-VAE decode of the 25 frames.
-  c2        (default; BASELINE.json configs[1])  SVD-XT UNet single chunk: 25 frames, 25 steps, no ControlNet/CAM.
-  ar_chunk  (configs[2]'s unit of work)          one autoregressive chunk: 30 AYS steps with ControlNet (7 frames)
-                                                 + 13 CAM mergers, decode 25 frames.
+DEFAULT workload = stage 1 of the 200-frame job (BASELINE.json configs[2]; SURVEY.md 8d "stage-1 frames/s"): 100 diffusion-stage
+frames at 576x1024 = chunk 0 (25 frames, 25 Euler-EDM steps, no ControlNet) + 5 autoregressive chunks (30 AlignYourSteps steps,
+ControlNet on the previous chunk's last 7 DECODED frames + 13 CAM mergers, 18 new frames each), every chunk decoded by the temporal
+VAE; CFG batch 2 x 25 frames per network evaluation at latent 72x128.  One "step" = ONE CHUNK of that sequence, in order
+(chunk 0, AR1 ... AR5, chunk 0 of the next video, ...): warm-up and timed steps walk the real sequence, so the control frames of
+every AR chunk are the decoded frames of the chunk before it.  value = frames that end up in the 100-frame videos (25 | 18 x 4 | 3 per
+chunk: the last AR chunk is cut by [:100], inference_i2v.py:190) / max-over-ranks time.
+  c2        BASELINE.json configs[1]: SVD-XT UNet single chunk, 25 frames, 25 steps, no ControlNet/CAM (parity-test case).
+  ar_chunk  one autoregressive chunk repeated (30 AYS steps, ControlNet + CAM, decode 25 frames).
+  c3        one step = a whole 100-frame stage-1 video.       enhance / vfi: the I2VGen-XL window pass / EMA-VFI.
 Weights: seeded random at the reference's exact architecture (no checkpoints offline; zero-inits un-zeroed).
-Inputs already resident in HBM when the timed region starts.  value = frames generated by all ranks / max-over-ranks time.
-Multi-GPU: the AR stage has a true chunk-to-chunk dependency; what shards without a collective is
-independent videos -> one replica chunk per rank, "scaling": "weak".  RCCL is used only for the timing barrier.
+Inputs already resident in HBM when the timed region starts.
+Multi-GPU (--gpus N > 1, default --parallelism job): ONE job strong-scaled -- the two CFG halves over a rank pair (one RCCL
+all-gather of the network output per Euler step) x frame<->pixel sequence parallelism inside each half (RCCL all-to-all around the
+temporal operators; SURVEY.md 8e options 1 + 2).  --parallelism replica: one independent video per GPU (weak scaling, no collective).
 
 The JSON line also carries
-  roofline     : dominant kernel (by summed device time), algorithmic FLOP / HIP-event time vs the 2.5 PFLOP/s bf16 MFMA peak
-  cpu_baseline : the CPU oracle (oracle/svd_oracle.py, a port of the reference path) timed on this host on a bounded sample.
+  roofline     : dominant kernel (by summed device time) of a SEPARATE traced AR chunk (HIP events around every GEMM / attention
+                 launch on the launch stream; the timed region itself is untraced): algorithmic FLOP / event time vs the 2.5 PFLOP/s
+                 16-bit MFMA peak, per-signature HBM bytes (rocprofv3 PMC passes, profiles/) next to the algorithmic bytes.
+  cpu_baseline : the CPU oracle (oracle/svd_oracle.py, a port of the reference path) timed on this host at the REAL spatial size
+                 (72x128 latent, CFG 2 x 2 frames; one 576x1024 frame decoded), extrapolated linearly over frames only.
 """
 import argparse
 import json
@@ -33,15 +42,15 @@ MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICRO
 
 
 class LaunchTrace:
-    """Per-launch HIP-event timing on the stream the kernels run on (torch's current stream)."""
+    """Per-launch HIP-event timing on the stream the kernels run on (torch's current stream).  Installed as ops.trace for ONE
+    separate chunk after the timed region (the timed region is untraced)."""
 
     def __init__(self):
-        self.records = []      # (name, flops, start_event, stop_event)
-        self._pool = []
+        self.records = []      # (name, signature, flops, bytes, start_event, stop_event)
 
     class _Ctx:
-        def __init__(self, tr, name, flops):
-            self.tr, self.name, self.flops = tr, name, flops
+        def __init__(self, tr, name, flops, sig, nbytes):
+            self.tr, self.name, self.flops, self.sig, self.nbytes = tr, name, flops, sig, nbytes
 
         def __enter__(self):
             self.s = torch.cuda.Event(enable_timing=True)
@@ -50,44 +59,54 @@ class LaunchTrace:
 
         def __exit__(self, *a):
             self.e.record()
-            self.tr.records.append((self.name, self.flops, self.s, self.e))
+            self.tr.records.append((self.name, self.sig, self.flops, self.nbytes, self.s, self.e))
 
-    def launch(self, name, flops):
-        return LaunchTrace._Ctx(self, name, flops)
+    def launch(self, name, flops, sig=None, nbytes=0.0):
+        return LaunchTrace._Ctx(self, name, flops, sig or name, nbytes)
 
     def summarize(self):
+        """{kernel name: [launches, flops, ms, {signature: [launches, flops, ms, algorithmic bytes per launch]}]}"""
         agg = {}
-        for name, flops, s, e in self.records:
+        for name, sig, flops, nbytes, s, e in self.records:
             ms = s.elapsed_time(e)
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a = agg.setdefault(name, [0, 0.0, 0.0, {}])
             a[0] += 1; a[1] += flops; a[2] += ms
+            b = a[3].setdefault(sig, [0, 0.0, 0.0, nbytes])
+            b[0] += 1; b[1] += flops; b[2] += ms
         return agg
 
 
-def pmc_traffic(trace_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    separate runs, gfx950 x2 read correction: tools/pmc_traffic.py -> profiles/*traffic*.json).  PMC cannot be sampled inside
-    this process, so the figure is the per-launch mean of the same kernel instantiation in the profiled run; None if absent."""
+def signature_traffic(sig):
+    """HBM bytes per launch of ONE GEMM signature from the committed rocprofv3 PMC passes (tools/pmc_signature.sh: the signature is
+    launched alone under `rocprofv3 --pmc FETCH_SIZE` and, separately, `--pmc WRITE_SIZE`; gfx950 x2 read correction of
+    MI355X_MICROARCH.md) -> profiles/*traffic_signatures*.json.  PMC cannot be sampled inside this process; None if absent."""
     import glob
-    import re
-    from streamingt2v_amd import lib as L
-    import ctypes as C
-    m = re.match(r"gemm_cfg(\d+)_mode(\d)", trace_name)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")))
-    if not files:
-        return None
-    kern = json.load(open(files[-1]))["kernels"]
-    if m:
-        bm, bn = C.c_int(), C.c_int()
-        L.lib.svd_gemm_config_info(int(m.group(1)), bm, bn, None, None)
-        pat = f"gemm {bm.value}x{bn.value} "
-        cands = [v for k, v in kern.items() if k.startswith(pat) and f"mode{m.group(2)}" in k]
-    else:
-        cands = [v for k, v in kern.items() if k.startswith(trace_name)]
-    if not cands:
-        return None
-    return {"bytes_per_launch": round(cands[0]["bytes_per_launch"]), "source": os.path.basename(files[-1]),
-            "note": "FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE, mean per launch of this kernel in the profiled run"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_signatures*.json")))
+    for f in reversed(files):
+        ent = json.load(open(f)).get("signatures", {}).get(sig)
+        if ent:
+            return dict(ent, source=os.path.basename(f))
+    return None
+
+
+def roofline_from_trace(trace):
+    agg = trace.summarize()
+    tot_ms = sum(v[2] for v in agg.values())
+    name, (cnt, flops, ms, sigs) = max(agg.items(), key=lambda kv: kv[1][2])
+    ach = flops / (ms * 1e-3) / 1e12
+    sig, (scnt, sflops, sms, sbytes) = max(sigs.items(), key=lambda kv: kv[1][2])
+    counted = signature_traffic(sig)
+    traffic = {"signature": sig, "launches": scnt, "avg_launch_ms": round(sms / scnt, 4), "TFLOP/s": round(sflops / (sms * 1e-3) / 1e12, 1),
+               "algorithmic_bytes_per_launch": round(sbytes), "counted_bytes_per_launch": None, "counted_over_algorithmic": None}
+    if counted:
+        traffic.update(counted_bytes_per_launch=round(counted["bytes_per_launch"]),
+                       counted_over_algorithmic=round(counted["bytes_per_launch"] / max(sbytes, 1.0), 3), source=counted["source"],
+                       note="FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE of this signature launched alone; algorithmic = A + W read once, C (+ residual) once")
+    return {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
+            "share_of_traced_time": round(ms / tot_ms, 3), "traced": "one AR chunk after the timed region",
+            "traced_kernels": {k: {"launches": v[0], "ms": round(v[2], 2), "TFLOP/s": round(v[1] / (v[2] * 1e-3) / 1e12, 1)}
+                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
 
 
 def build_models(workload, device):
@@ -95,7 +114,7 @@ def build_models(workload, device):
     from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VideoDecoder
     from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
     from streamingt2v_amd.wrappers import StreamingWrapper
-    use_cn = workload == "ar_chunk"
+    use_cn = workload in ("ar_chunk", "stage1", "c3")
     cfg = UNetConfig(controlnet_mode=use_cn)
     unet = VideoUNet(cfg)
     unet.load_state_dict(init_by_name(unet.spec(), seed=33, device=device), device=device)
@@ -121,22 +140,24 @@ def synthetic_inputs(device, seed):
     return c, uc, ctrl, r(T, 4, h, w)
 
 
-def cpu_baseline(workload, budget_note=True):
-    """Time the CPU oracle on a bounded sample of the same workload and extrapolate to frames/s.
-    Sample: ONE full-architecture VideoUNet forward (all 1.59 B parameters, fp32) on CFG batch 2 x 2 frames at a
-    24x32 latent (1/150 of the tokens of the real forward) + one 1-frame-group VAE decode at 64x128.  The per-token
-    cost is scaled linearly to 50 frames x 72x128 (attention's quadratic term is therefore UNDER-counted, i.e. the CPU
-    number is optimistic), steps x forward + 25-frame decode gives seconds per chunk."""
+def cpu_baseline(workload):
+    """Time the CPU oracle (a port of the reference path, pinned against the unmodified reference: oracle/make_golden*.py) on a bounded
+    sample at the REAL spatial size and extrapolate over FRAMES only (every operator is linear in the number of frames except the
+    temporal attention / (3,1,1) convolutions, < 1 % of the FLOPs):
+      * one full-architecture VideoUNet forward (1.59 B parameters, fp32) on CFG 2 x 2 frames at the 72x128 latent -- the N = 9216
+        spatial attention, the 295-MB-class activations and the cache behaviour of the real forward are all in the sample;
+      * one frame decoded by the temporal VAE at 576x1024.
+    A forward of the job has 50 frames (x 12.5); AR chunks add ControlNet + CAM: x 181.96 / 159.9 algorithmic FLOP.
+    The reference's own modules, timed in the build container: profiles/r02_cpu_reference_forward.txt."""
     from oracle import svd_oracle as O
     from streamingt2v_amd.params import init_by_name
     from streamingt2v_amd.temporal_ae import VideoDecoder
     from streamingt2v_amd.video_model import UNetConfig, VideoUNet
     cores = min(os.cpu_count() or 1, 32)      # more threads than this slow the fp32 CPU kernels down on a 256-core host
     torch.set_num_threads(cores)
-    steps = 25 if workload == "c2" else 30
     with torch.no_grad():
         sd = init_by_name(VideoUNet(UNetConfig(controlnet_mode=False)).spec(), seed=33)
-        T, h, w = 2, 24, 32
+        T, h, w = 2, LAT_H, LAT_W
         g = torch.Generator(); g.manual_seed(0)
         x = torch.randn(2 * T, 8, h, w, generator=g)
         t0 = time.time()
@@ -145,18 +166,22 @@ def cpu_baseline(workload, budget_note=True):
         t_unet = time.time() - t0
         del sd
         sd = init_by_name(VideoDecoder().spec(), seed=35)
-        zh, zw = 8, 16
         t0 = time.time()
-        O.video_decoder(sd, O.VaeCfg(), torch.randn(1, 4, zh, zw, generator=g), 1)
+        O.video_decoder(sd, O.VaeCfg(), torch.randn(1, 4, h, w, generator=g), 1)
         t_dec = time.time() - t0
-    tok_ratio = (50 * LAT_H * LAT_W) / (2 * T * h * w)
-    fwd_full = t_unet * tok_ratio
-    dec_frame = t_dec * (LAT_H * LAT_W) / (zh * zw)
-    chunk_s = steps * fwd_full + T_FRAMES * dec_frame
-    return {"value": T_FRAMES / chunk_s, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle VideoUNet fwd 2x{T} frames @{h}x{w} latent ({t_unet:.1f}s) + VideoDecoder 1 frame @{8*zh}x{8*zw} "
-                      f"({t_dec:.1f}s), scaled linearly in tokens to 50 frames @72x128 x {steps} steps + 25-frame decode "
-                      f"=> {chunk_s:.0f}s per 25-frame chunk"}
+    fwd_c2 = t_unet * (2 * T_FRAMES) / (2 * T)                    # 50 frames
+    fwd_ar = fwd_c2 * 181.96 / 159.9
+    dec_chunk = T_FRAMES * t_dec
+    if workload == "c2":
+        chunk_s, frames, what = 25 * fwd_c2 + dec_chunk, T_FRAMES, "25-step chunk without ControlNet"
+    elif workload == "ar_chunk":
+        chunk_s, frames, what = 30 * fwd_ar + dec_chunk, T_FRAMES, "30-step AR chunk"
+    else:
+        chunk_s, frames, what = (25 * fwd_c2 + dec_chunk) + 5 * (30 * fwd_ar + dec_chunk), 100, "100-frame stage 1 (chunk 0 + 5 AR chunks)"
+    return {"value": frames / chunk_s, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle VideoUNet forward, CFG 2 x {T} frames @ {h}x{w} latent (full size): {t_unet:.1f} s; VideoDecoder 1 frame @ 576x1024: "
+                      f"{t_dec:.1f} s; x12.5 over frames => {fwd_c2:.0f} s per 50-frame forward (x1.138 with ControlNet + CAM), "
+                      f"{dec_chunk:.0f} s per 25-frame decode => {chunk_s:.0f} s per {what}"}
 
 
 def run_enhance(args, rank, world, device):
@@ -179,7 +204,7 @@ def run_enhance(args, rank, world, device):
     conds = []
     for _ in range(world):
         il, emb, text = rn(1, 4, chunk, H, W) * 0.7, rn(1, cd), rn(1, 77, cd)
-        conds.append(dict(fps=torch.tensor([16, 16]), image_latents=torch.cat([il, il]),
+        conds.append(dict(fps=torch.tensor([38, 38]), image_latents=torch.cat([il, il]),
                           image_embeddings=torch.cat([torch.zeros_like(emb), emb]), text=torch.cat([torch.zeros_like(text), text])))
     video, noise = rn(1, 4, n_frames, H, W) * 0.5, rn(1, 4, n_frames, H, W)
     n_inf = args.denoise_steps or 30
@@ -211,17 +236,7 @@ def run_enhance(args, rank, world, device):
     ops.trace = None
     assert torch.isfinite(out).all()
     if rank == 0:
-        roof = None
-        if trace is not None:
-            agg = trace.summarize()
-            tot_ms = sum(v[2] for v in agg.values())
-            name, (cnt, flops, ms) = max(agg.items(), key=lambda kv: kv[1][2])
-            ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
-                    "share_of_traced_time": round(ms / tot_ms, 3),
-                    "traced_kernels": {k: {"launches": v[0], "ms": round(v[2], 2), "TFLOP/s": round(v[1] / (v[2] * 1e-3) / 1e12, 1)}
-                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
+        roof = roofline_from_trace(trace) if trace is not None else None
         print(json.dumps({
             "metric": "enhanced frames/sec (720x1280)", "value": round(args.steps * n_frames / dt, 4), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
@@ -285,6 +300,96 @@ def run_c3(args, rank, world, device):
         dist.destroy_process_group()
 
 
+class Stage1Stream:
+    """Walks the chunk sequence of consecutive 100-frame stage-1 jobs: chunk 0, AR1 .. AR5, chunk 0 of the next video, ...
+    (StreamingSVD.image_to_video + _autoregressive_generation, diffusion_trainer/streaming_svd.py:293-402, one chunk per step())."""
+    KEPT = (25, 18, 18, 18, 18, 3)       # frames of each chunk that end up in video[:100] (inference_i2v.py:190)
+
+    def __init__(self, model, c, uc, noises):
+        self.model, self.c, self.uc, self.noises = model, c, uc, noises
+        self.i, self.chunks, self.video_u8 = 0, None, None
+
+    def step(self):
+        m, k = self.model, self.i % 6
+        with torch.no_grad():
+            if k == 0:
+                first = m.quantize_like_pil(m._generate_initial_chunk(self.c, self.uc, self.noises[0]))
+                self.chunks = [first]
+            else:
+                ctrl = m.extract_ctrl_frames(self.chunks[-1], m.num_conditional_frames)
+                result = m._generate_conditional_output(self.c, self.uc, ctrl, self.noises[k])
+                self.chunks.append(result[m.num_conditional_frames:])
+                if k == 5:
+                    self.video_u8 = m.to_uint8_video(torch.cat(self.chunks, 0)[:100])
+        self.i += 1
+        return self.KEPT[k]
+
+
+def run_stage1(args, rank, world, device):
+    """Default workload: stage 1 of the 200-frame job, one step = one chunk of the real autoregressive sequence (see the module docstring)."""
+    from streamingt2v_amd import ops, parallel
+    from streamingt2v_amd.sampling import AlignYourSteps, EulerEDMSampler
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    plan = parallel.JobPlan.from_env(world, args.parallelism)          # CFG pair x sequence-parallel group (or replicas)
+    wrapper, vae = build_models("stage1", device)
+    plan.attach(wrapper, vae)
+    sampler = EulerEDMSampler(num_steps=args.denoise_steps or 30, num_frames=T_FRAMES, min_scale=1.5, max_scale=3.0,
+                              discretization=AlignYourSteps(), cfg_exchange=plan.cfg_exchange)
+    model = StreamingSVD(wrapper, vae, sampler)
+    if args.denoise_steps:
+        model.initial_num_steps = args.denoise_steps
+    c, uc, _, _ = synthetic_inputs(device, 33 + plan.video_id)
+    g = torch.Generator(device=device); g.manual_seed(133 + plan.video_id)
+    noises = [torch.randn(T_FRAMES, 4, LAT_H, LAT_W, generator=g, device=device) for _ in range(6)]
+    stream = Stage1Stream(model, c, uc, noises)
+
+    def sync_all():
+        torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stream.step()
+    sync_all()
+    t0 = time.perf_counter()
+    kept = 0
+    for _ in range(args.steps):
+        kept += stream.step()
+    sync_all()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+    assert all(torch.isfinite(ch).all() for ch in stream.chunks)
+    roof = None
+    if not args.no_trace and rank == 0 and world == 1:
+        # separate traced pass: ONE AR chunk (the next chunk of the sequence if it is an AR chunk, else skip chunk 0 first)
+        if stream.i % 6 == 0:
+            stream.step()
+        trace = LaunchTrace()
+        ops.trace = trace
+        stream.step()
+        torch.cuda.synchronize()
+        ops.trace = None
+        roof = roofline_from_trace(trace)
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline("stage1")
+            except Exception as e:   # the GPU measurement above must never be lost to a host-side problem
+                cpu = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"FAILED: {e!r}"}
+        print(json.dumps({
+            "metric": "generated frames/sec (576x1024)", "value": round(plan.n_videos * kept / dt, 4), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": plan.scaling, "vs_baseline": None, "dtype": args.dtype.replace("fp16", "f16"), "data": "synthetic",
+            "config": {"workload": "StreamingSVD 200-frame job, stage 1 (100 frames @576x1024, BASELINE configs[2]): one step = one chunk of the "
+                                   "autoregressive sequence chunk 0 (25 EDM steps) | AR1..AR5 (30 AYS steps, ControlNet(7 decoded frames) + CAM), "
+                                   "CFG 2 x 25 frames @ latent 72x128 per evaluation, temporal-VAE decode of every chunk",
+                       "frames_kept_per_chunk": list(Stage1Stream.KEPT), "frames_in_timed_steps": kept, "latent": [LAT_H, LAT_W],
+                       "denoise_steps": [args.denoise_steps or 25, args.denoise_steps or 30],
+                       "parallelism": plan.describe(), "weights": "seeded random, reference architecture (1.59 B + 0.67 B + 64 M parameters)"},
+            "roofline": roof, "cpu_baseline": cpu}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def run_vfi(args, rank, world, device):
     """--workload vfi: one step = the frame interpolation of one 100-frame 720x1280 video to 200 frames
     (inference_i2v.py:252): 99 EMA-VFI inferences with fast TTA, each with its uint8 conversion; the frames are resident in HBM as
@@ -332,13 +437,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "ar_chunk", "c3", "enhance", "vfi"])
-    ap.add_argument("--parallelism", default="replica", choices=["replica", "cfg"],
-                    help="replica: one video per GPU (weak scaling, no collective); cfg: GPU pairs split the CFG halves of one video")
+    ap.add_argument("--workload", default="stage1", choices=["stage1", "c2", "ar_chunk", "c3", "enhance", "vfi"])
+    ap.add_argument("--parallelism", default="job", choices=["job", "replica", "cfg"],
+                    help="job (stage1): ONE job over all GPUs, CFG pair x frame<->pixel sequence parallelism (strong scaling); "
+                         "replica: one video per GPU (weak scaling, no collective); cfg (c2 / ar_chunk): GPU pairs split the CFG halves of one video")
     ap.add_argument("--denoise-steps", type=int, default=None, help="override Euler steps per chunk (debug only: INVALID for reporting)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
-                    help="16-bit element type of the kernels (fp32 accumulation either way): bf16 = north_star default; fp16 = the "
-                         "reference's own autocast precision, the one that meets the 1e-3 parity target (DESIGN.md 4)")
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="16-bit element type of the kernels (fp32 accumulation either way, same MFMA rate): fp16 (default) = the reference's "
+                         "own autocast precision (config.yaml:8), the one the parity tests assert north_star's tolerance in; bf16 selectable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true")
     args = ap.parse_args()
@@ -354,6 +460,8 @@ def main():
     from streamingt2v_amd.streaming_svd import StreamingSVD
     parallel.init_from_env(backend="nccl", device=device)
     ops.set_element_dtype(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
+    if args.workload == "stage1":
+        return run_stage1(args, rank, world, device)
     if args.workload == "enhance":
         return run_enhance(args, rank, world, device)
     if args.workload == "c3":
@@ -364,6 +472,8 @@ def main():
     # parallelism: "replica" = one independent video per rank (no data-path collective);
     #              "cfg"     = ranks (2k, 2k+1) split the two CFG halves of one video, one RCCL all-gather per Euler step
     cfg_ex, n_videos, video_id = None, world, rank
+    if args.parallelism == "job":
+        args.parallelism = "replica"            # c2 / ar_chunk are single-chunk parity workloads: replicas unless --parallelism cfg
     if args.parallelism == "cfg":
         import torch.distributed as dist
         assert world % 2 == 0, "--parallelism cfg needs an even number of GPUs"
@@ -405,18 +515,7 @@ def main():
     dt = parallel.max_over_ranks(dt, device=device)
 
     if rank == 0:
-        roof = None
-        if trace is not None:
-            agg = trace.summarize()
-            tot_ms = sum(v[2] for v in agg.values())
-            name, (cnt, flops, ms) = max(agg.items(), key=lambda kv: kv[1][2])
-            ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(name), "launches": cnt,
-                    "avg_launch_ms": round(ms / cnt, 4),
-                    "share_of_traced_time": round(ms / tot_ms, 3),
-                    "traced_kernels": {k: {"launches": v[0], "ms": round(v[2], 2), "TFLOP/s": round(v[1] / (v[2] * 1e-3) / 1e12, 1)}
-                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
+        roof = roofline_from_trace(trace) if trace is not None else None
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:

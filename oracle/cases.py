@@ -268,3 +268,32 @@ def fullarch_small_inputs():
     pair = torch.nn.functional.interpolate(low, scale_factor=8, mode="bicubic", align_corners=False).clamp(0, 1)[:, :, 4:4 + 64, 7:7 + 96].contiguous()
     return dict(z=torch.randn(3, 4, 8, 8, generator=g), x_enc=torch.rand(1, 3, 64, 64, generator=g) * 2 - 1,
                 img0=pair[:, :3].contiguous(), img1=pair[:, 3:].contiguous())
+
+
+# ---- the shipped architecture at the SHIPPED PROBLEM SIZE (oracle/make_golden_fullsize.py; SURVEY 8a row A5 / A11 sizes) ----
+FULLSIZE_CASE = dict(T=25, Tc=7, h=72, w=128, seed_unet=33, seed_cn=34)
+
+
+def fullsize_inputs():
+    """x is what Denoiser hands the network (x * c_in: unit variance); t = c_noise = 0.25 ln(sigma), one value per CFG half as in
+    the sampler (sigma = 7.47 here, a mid-schedule AYS value); concat = cond-frame latents (0.18215-scaled VAE mean / zeros for uc)."""
+    g = _gen(7272)
+    c = FULLSIZE_CASE
+    T, h, w = c["T"], c["h"], c["w"]
+    F = 2 * T
+    concat = torch.randn(1, 4, h, w, generator=g).mul(0.8).repeat(T, 1, 1, 1)
+    return dict(x=torch.randn(F, 4, h, w, generator=g), t=torch.full((F,), 0.25 * 2.0112),
+                concat=torch.cat((torch.zeros(T, 4, h, w), concat)),
+                crossattn=torch.cat((torch.zeros(T, 1, 1024), torch.randn(1, 1, 1024, generator=g).repeat(T, 1, 1))),
+                vector=(torch.randn(1, 768, generator=g) * 0.5).repeat(F, 1),
+                ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
+
+
+def fullsize_vae_inputs():
+    g = _gen(7373)
+    return dict(z=torch.randn(2, 4, 72, 128, generator=g))
+
+
+def fullsize_pixel_subset(n_pixels):
+    """seeded random 1/16 of the pixel positions of a frame (sorted), shared by generator and test."""
+    return torch.randperm(n_pixels, generator=_gen(7474))[: n_pixels // 16].sort().values

@@ -404,11 +404,12 @@ def vscaling_edm(sigma):
     return 1.0 / (sigma ** 2 + 1.0), -sigma / (sigma ** 2 + 1.0) ** 0.5, 1.0 / (sigma ** 2 + 1.0) ** 0.5, 0.25 * sigma.log()
 
 
-def euler_edm_sample(network, x, cond, uc, num_steps, num_frames, min_scale=1.5, max_scale=3.0):
+def euler_edm_sample(network, x, cond, uc, num_steps, num_frames, min_scale=1.5, max_scale=3.0, sigmas=None):
     """EulerEDMSampler.__call__ (s_churn 0) + Denoiser.forward + LinearPredictionGuider,
     sampling.py:41-52,93-130 ; denoiser.py:23-39 ; guiders.py:60-99.
-    network(x_in[2T..], c_noise[2T], cond_dict) -> eps-like output [2T..]."""
-    sigmas = ays_sigmas(num_steps)
+    network(x_in[2T..], c_noise[2T], cond_dict) -> eps-like output [2T..].
+    sigmas: None = AlignYourSteps(num_steps) (the AR chunks); pass edm_sigmas(n) for the first chunk's Karras schedule."""
+    sigmas = ays_sigmas(num_steps) if sigmas is None else sigmas.double()
     x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     x = x.float()
     s_in = x.new_ones([x.shape[0]])

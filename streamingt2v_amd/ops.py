@@ -151,7 +151,14 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
     args.tile_cfg = tile_cfg
     if trace is not None:
         cfg = tile_cfg or _lib.svd_gemm_pick_config(C.byref(args))
-        with trace.launch(f"gemm_cfg{cfg}_mode{args.a_mode}", flops=2.0 * M * N * K):
+        # algorithmic HBM bytes of this launch: the source activation and the weights read once, the output (and the residual /
+        # blend operands) moved once
+        esz = 2
+        src_rows = a.shape[0] if conv is None else conv["frames"] * conv["hin"] * conv["win"]
+        src_cols = K if (conv is None and temporal is None) else args.cin
+        nbytes = (src_rows * src_cols + N * K) * esz + M * nout * (4 if out.dtype == torch.float32 else esz)
+        nbytes += M * nout * esz * ((residual is not None) + (blend is not None))
+        with trace.launch(f"gemm_cfg{cfg}_mode{args.a_mode}", flops=2.0 * M * N * K, sig=gemm_signature(args), nbytes=float(nbytes)):
             check(_lib.svd_gemm(C.byref(args), _stream()), f"svd_gemm(M={M},N={N},K={K},mode={args.a_mode})")
         return out
     check(_lib.svd_gemm(C.byref(args), _stream()), f"svd_gemm(M={M},N={N},K={K},mode={args.a_mode})")
@@ -183,14 +190,15 @@ def softmax_rows(s, out, scale):
     return out
 
 
-def _gn_workspace(device, frames, channels):
+def _gn_workspace(device, frames, channels, nstat=1, groups=32):
+    """(partial sums, stats) workspaces of svd_groupnorm_*: partial >= svd_groupnorm_partial_elems, stats = [nstat][groups][2] floats."""
     need = int(_lib.svd_groupnorm_partial_elems(frames, channels))
-    key = device
-    ws = _gn_ws.get(key)
-    if ws is None or ws[0].numel() < need:
+    need_stats = 2 * groups * nstat
+    ws = _gn_ws.get(device)
+    if ws is None or ws[0].numel() < need or ws[1].numel() < need_stats:
         ws = (torch.empty(max(need, 1 << 20), dtype=torch.float32, device=device),
-              torch.empty(65536, dtype=torch.float32, device=device))
-        _gn_ws[key] = ws
+              torch.empty(max(need_stats, 65536), dtype=torch.float32, device=device))
+        _gn_ws[device] = ws
     return ws
 
 
@@ -199,7 +207,8 @@ def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False
     rows, ld = _rows_ld(x)
     Cc = x.shape[1]
     assert rows == frames * pix
-    partial, stats = _gn_workspace(x.device, frames, Cc)
+    assert frames % frames_per_stat == 0
+    partial, stats = _gn_workspace(x.device, frames, Cc, frames // frames_per_stat, groups)
     check(_lib.svd_groupnorm_stats(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, float(eps), _p(partial),
                                    _p(stats), _dt(x), _stream()), "svd_groupnorm_stats")
     if out is None:

@@ -67,3 +67,145 @@ class CfgPairExchange:
         parts = [torch.empty_like(net_half), torch.empty_like(net_half)]
         dist.all_gather(parts, net_half.contiguous(), group=self.group)
         return torch.cat(parts, 0)
+
+
+def split_sizes(n, parts):
+    """Contiguous near-even split of n items into `parts` ranges: the first n % parts ranges get one more (25 frames / 4 -> 7 6 6 6)."""
+    q, r = divmod(n, parts)
+    return [q + (1 if i < r else 0) for i in range(parts)]
+
+
+class SeqParallel:
+    """Frame <-> pixel sequence parallelism inside ONE forward of the denoiser (SURVEY.md 8e option 2).
+
+    Every spatial operator of the UNet / ControlNet (2-D convolutions, spatial attention, per-frame GroupNorm, LayerNorm, feed-forward)
+    is independent per FRAME; every temporal operator (temporal attention, (3,1,1) convolutions, the CAM merger attention) is
+    independent per PIXEL.  Rank r of the group therefore holds a contiguous range of the T frames of each batch element for the spatial
+    operators ("frame layout": rows (b, t_local, pixel)), and a contiguous range of the pixels of ALL frames for the temporal ones
+    ("pixel layout": rows (b, t, pixel_local)); `to_pixels` / `to_frames` move a token matrix between the two with ONE all-to-all
+    (RCCL over xGMI; every rank exchanges 1/S^2 of the tensor with every other rank, all links busy).  The only reductions are the
+    5-D GroupNorm statistics, which pool over frames AND pixels: `allreduce_sums` adds the per-rank (sum, sum of squares) pairs
+    (2 x 32 groups x batch doubles).
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self.size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    # ---- index bookkeeping -------------------------------------------------------------------------------------------------------
+    def frame_counts(self, T):
+        return split_sizes(T, self.size)
+
+    def frame_range(self, T):
+        c = self.frame_counts(T)
+        lo = sum(c[:self.rank])
+        return lo, lo + c[self.rank]
+
+    def pix_local(self, pix):
+        assert pix % self.size == 0, f"{pix} pixels do not split over {self.size} ranks"
+        return pix // self.size
+
+    def take_frames(self, v, B, T, per=1):
+        """rows (b, t, per) of a [B*T*per, ...] tensor -> this rank's frames (b, t_local, per)."""
+        lo, hi = self.frame_range(T)
+        return v.reshape(B, T, per, *v.shape[1:])[:, lo:hi].reshape(B * (hi - lo) * per, *v.shape[1:]).contiguous()
+
+    # ---- layout changes ----------------------------------------------------------------------------------------------------------
+    def to_pixels(self, x, B, T, pix):
+        """frame layout [B * Tl * pix, C] -> pixel layout [B * T * pixl, C]."""
+        S, C = self.size, x.shape[1]
+        cnt, pl = self.frame_counts(T), self.pix_local(pix)
+        tl = cnt[self.rank]
+        send = x.reshape(B, tl, S, pl, C).permute(2, 0, 1, 3, 4).contiguous()            # [dest][b][t_local][pixel_local][c]
+        recv = torch.empty((B * T * pl, C), dtype=x.dtype, device=x.device)
+        dist.all_to_all_single(recv, send.reshape(-1, C), [B * c * pl for c in cnt], [B * tl * pl] * S, group=self.group)
+        if B == 1:
+            return recv                                                                   # source order == frame order
+        parts = recv.split([B * c * pl for c in cnt], 0)
+        return torch.cat([p.reshape(B, c, pl, C) for p, c in zip(parts, cnt)], 1).reshape(B * T * pl, C)
+
+    def to_frames(self, x, B, T, pix):
+        """pixel layout [B * T * pixl, C] -> frame layout [B * Tl * pix, C] (inverse of to_pixels)."""
+        S, C = self.size, x.shape[1]
+        cnt, pl = self.frame_counts(T), self.pix_local(pix)
+        tl = cnt[self.rank]
+        if B == 1:
+            send = x
+        else:
+            xs = x.reshape(B, T, pl, C).split(cnt, 1)
+            send = torch.cat([p.reshape(-1, C) for p in xs], 0)
+        recv = torch.empty((S, B, tl, pl, C), dtype=x.dtype, device=x.device)             # [source = pixel range][b][t_local][pixel_local]
+        dist.all_to_all_single(recv.reshape(-1, C), send.contiguous(), [B * tl * pl] * S, [B * c * pl for c in cnt], group=self.group)
+        return recv.permute(1, 2, 0, 3, 4).reshape(B * tl * pix, C)
+
+    # ---- small collectives ---------------------------------------------------------------------------------------------------------
+    def allreduce_sums(self, sums):
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        return sums
+
+    def gather_frames(self, x, B, T, per):
+        """frame layout [B * Tl * per, C] of every rank -> all frames [B * T * per, C] on every rank (uneven ranges are padded to the
+        largest one for the collective: NCCL / RCCL all-gather wants equal sizes)."""
+        cnt = self.frame_counts(T)
+        tmax, C = max(cnt), x.shape[1]
+        tl = cnt[self.rank]
+        buf = x.reshape(B, tl * per, C)
+        if tl < tmax:
+            buf = torch.cat([buf, buf.new_zeros(B, (tmax - tl) * per, C)], 1)
+        parts = [torch.empty_like(buf) for _ in range(self.size)]
+        dist.all_gather(parts, buf.contiguous(), group=self.group)
+        return torch.cat([p[:, : c * per] for p, c in zip(parts, cnt)], 1).reshape(B * T * per, C)
+
+
+class JobPlan:
+    """How the ranks of one node share ONE stage-1 job (bench.py --parallelism job) -- or do not (replica).
+
+    world = 1: everything local.  world = 2: the CFG pair (ranks 0 | 1 evaluate the unconditional | conditional half, one all-gather
+    of the 3.7 MB network output per Euler step).  world = 4 / 8: CFG pair x sequence parallelism of degree world / 2 inside each half:
+    rank = 2 * sp_rank + cfg_half, i.e. the SP group of a half is {half, half + 2, half + 4, ...}.  The temporal-VAE decode of a chunk
+    is sharded by its independent 8-frame groups over all ranks (broadcast of each group's frames from its owner).
+    Amdahl: the Euler update, conditioning glue and the per-chunk hand-over are replicated (< 1 % of a chunk)."""
+
+    def __init__(self, world=1, rank=0, mode="job"):
+        self.world, self.rank, self.mode = world, rank, mode
+        self.cfg_exchange, self.sp, self.n_videos, self.video_id = None, None, 1, 0
+        self.decode_group = None
+        if world == 1:
+            return
+        if mode == "replica":
+            self.n_videos, self.video_id = world, rank
+            return
+        assert world % 2 == 0, "--parallelism job needs an even number of GPUs (CFG pair x sequence parallelism)"
+        pairs = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]           # every rank creates every group, same order
+        halves = [dist.new_group(list(range(h, world, 2))) for h in (0, 1)] if world > 2 else [None, None]
+        self.cfg_exchange = CfgPairExchange(pairs[rank // 2])
+        if world > 2:
+            self.sp = SeqParallel(halves[rank % 2])
+        self.decode_group = dist.group.WORLD
+
+    @classmethod
+    def from_env(cls, world, mode):
+        rank = dist.get_rank() if (dist.is_initialized() and world > 1) else 0
+        return cls(world, rank, mode)
+
+    @property
+    def scaling(self):
+        return "weak" if (self.mode == "replica" and self.world > 1) else "strong"
+
+    def attach(self, wrapper, vae):
+        """Give the networks their share of the plan: the StreamingWrapper runs its forward sequence-parallel over `sp`; the decoder
+        shards its frame groups over `decode_group`."""
+        wrapper.sp = self.sp
+        if hasattr(vae, "decode_group"):
+            vae.decode_group = self.decode_group if self.mode != "replica" else None
+
+    def describe(self):
+        if self.world == 1:
+            return "single GPU"
+        if self.mode == "replica":
+            return f"replica-per-gpu x{self.world} (independent videos, no data-path collective)"
+        sp = self.sp.size if self.sp else 1
+        return (f"one job over {self.world} GPUs: CFG pair (RCCL all-gather of the network output per Euler step) x frame<->pixel sequence "
+                f"parallelism of degree {sp} (RCCL all-to-all around the temporal operators, all-reduce of the 5-D GroupNorm sums), "
+                f"decode frame groups sharded over all ranks")

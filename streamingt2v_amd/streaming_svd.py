@@ -28,6 +28,7 @@ class StreamingSVD:
         self.scale_factor = scale_factor
         self.num_conditional_frames = num_conditional_frames
         self.use_memopt = use_memopt
+        self.initial_num_steps = 25        # diffusers StableVideoDiffusionPipeline default num_inference_steps (streaming_svd.py:390)
 
     @torch.no_grad()
     def decode_first_stage(self, z, clamp=False):
@@ -51,12 +52,13 @@ class StreamingSVD:
         return self.decode_first_stage(samples_z, clamp=True)          # torch.clamp(-1, 1) fused (streaming_svd.py:220)
 
     @torch.no_grad()
-    def _generate_initial_chunk(self, c, uc, noise, num_steps=25, min_scale=1.0, max_scale=3.0):
+    def _generate_initial_chunk(self, c, uc, noise, num_steps=None, min_scale=1.0, max_scale=3.0):
         """Chunk 0 natively: the reference delegates the first 25 frames to diffusers'
         StableVideoDiffusionPipeline (streaming_svd.py:388-390) -- the same UNet without ControlNet/CAM, an Euler step on
         the Karras/EDM schedule (25 steps) and per-frame guidance 1.0 -> 3.0, decoded in groups of 8 (decode_chunk_size=8)."""
         from .sampling import EDMDiscretization
         T = self.sampler.guider.num_frames
+        num_steps = num_steps or self.initial_num_steps
         sampler = EulerEDMSampler(num_steps=num_steps, num_frames=T, min_scale=min_scale, max_scale=max_scale,
                                   discretization=EDMDiscretization(), cfg_exchange=self.sampler.cfg_exchange)
         x = noise.clone().float().contiguous()

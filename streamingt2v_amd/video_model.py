@@ -653,10 +653,12 @@ class ControlNet(_EncoderBase):
         """The image-condition embedding depends only on ctrl_frames, not on sigma: it is computed once per
         distinct input tensor and reused across the Euler steps of a chunk (the reference recomputes it every
         step, controlnet.py:520; the values are identical)."""
-        key = (controlnet_cond.data_ptr(), tuple(controlnet_cond.shape), controlnet_cond._version)
-        if self._cond_cache is None or self._cond_cache[0] != key:
-            self._cond_cache = (key, self.controlnet_cond_embedding.forward(controlnet_cond)[0])
-        return self._cond_cache[1]
+        c = self._cond_cache
+        if c is None or c[0] is not controlnet_cond or c[1] != controlnet_cond._version:
+            # the cache keeps the input tensor alive: identity (not address) decides, so a freed-and-reallocated buffer of the
+            # next video can never alias a stale embedding
+            self._cond_cache = c = (controlnet_cond, controlnet_cond._version, self.controlnet_cond_embedding.forward(controlnet_cond)[0])
+        return c[2]
 
     def forward_tokens(self, x_tok, timesteps, controlnet_cond, context, y, T, H, W):
         F = timesteps.numel()

@@ -44,16 +44,19 @@ class StreamingWrapper:
             # ... and the pixel-space control frames, repeated for both CFG halves (wrappers.py:45-48)
             # "(2 B) F ..." in the reference (B = 1 video, CFG batch 2); one copy per batch element here so that a rank
             # holding a single CFG half (parallel.CfgPairExchange) repeats once
-            cond = ctrl_frames.repeat(batch_size // ctrl_frames.shape[0], *([1] * (ctrl_frames.dim() - 1))).flatten(0, 1)
-            cond = self._cond_cached(ctrl_frames, cond)
+            cond = self._cond_cached(ctrl_frames, batch_size)
             hs_c, mid_c = self.controlnet.forward_tokens(x_ctrl, t_ctrl, cond, ctx_ctrl, y_ctrl, Tc, H, W)
         return self.diffusion_model.forward_tokens(x_tok, t, context, y, T, H, W, hs_c, mid_c, Tc)
 
-    def _cond_cached(self, ctrl_frames, cond):
-        # keep ONE repeated tensor per ctrl_frames object so ControlNet.embed_condition can recognise it
-        key = (ctrl_frames.data_ptr(), tuple(ctrl_frames.shape), ctrl_frames._version, tuple(cond.shape))
-        if getattr(self, "_cond_key", None) != key:
-            self._cond_key, self._cond_val = key, cond.float().contiguous()
+    def _cond_cached(self, ctrl_frames, batch_size):
+        # ONE repeated fp32 tensor per ctrl_frames OBJECT (built on a miss only) so ControlNet.embed_condition can recognise it.  The
+        # cache holds a reference to ctrl_frames itself and compares identity + in-place version: a (data_ptr, shape, version) key can
+        # collide once the tensor is freed and the caching allocator hands the same address to the next video's control frames.
+        held = getattr(self, "_cond_src", None)
+        if held is None or held[0] is not ctrl_frames or held[1] != ctrl_frames._version or held[2] != batch_size:
+            cond = ctrl_frames.repeat(batch_size // ctrl_frames.shape[0], *([1] * (ctrl_frames.dim() - 1))).flatten(0, 1)
+            self._cond_src = (ctrl_frames, ctrl_frames._version, batch_size)
+            self._cond_val = cond.float().contiguous()
         return self._cond_val
 
     # ---- reference-shaped entry point ------------------------------------------------------------------------

@@ -1,0 +1,103 @@
+"""Parity at the SHIPPED ARCHITECTURE AND PROBLEM SIZE against the REFERENCE's own outputs (tests/golden/*_fullsize.pt, written by
+oracle/make_golden_fullsize.py from the unmodified reference modules on CPU):
+
+  * StreamingWrapper.forward, CFG 2 x 25 frames @ 72x128 latent, ControlNet on 2 x 7 control frames of 576x1024   
+  * VideoDecoder, 2 frames -> 576x1024 pixels (fp32 in the reference)                                              (row A11)
+
+    python tools/fullsize_parity.py [--dtype bf16|fp16|both] [--which wrapper|vae|both]
+
+Prints per-frame L2 (RMS error per frame, absolute on the network-output / [-1,1]-pixel scale, and relative).  The functions are also
+what tests/test_gpu_fullsize_parity.py asserts on.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def frame_errors(out, ref):
+    """per-frame RMS error, per-frame RMS of the reference, correlation."""
+    out, ref = out.float().cpu(), ref.float().cpu()
+    e = (out - ref).flatten(1).pow(2).mean(1).sqrt()
+    r = ref.flatten(1).pow(2).mean(1).sqrt()
+    corr = torch.corrcoef(torch.stack([out.flatten(), ref.flatten()]))[0, 1].item()
+    return dict(abs_max=e.max().item(), abs_mean=e.mean().item(), rel_max=(e / r).max().item(), ref_rms=r.mean().item(), corr=corr)
+
+
+def wrapper_fullsize(dtype, device="cuda", sds=None):
+    from oracle.cases import FULLSIZE_CASE as c, fullsize_inputs
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    torch.set_grad_enabled(False)
+    ops.set_element_dtype(DT[dtype])
+    gold = torch.load(os.path.join(GOLD, "wrapper_fullsize.pt"))
+    cfg = UNetConfig()
+    unet, cn = VideoUNet(cfg), ControlNet(cfg)
+    if sds is None:
+        sds = {}
+    if "u" not in sds:             # by-name CPU initialisation of 2.27 B parameters takes a minute: shared between the element types
+        sds["u"], sds["c"] = init_by_name(unet.spec(), seed=c["seed_unet"]), init_by_name(cn.spec(), seed=c["seed_cn"])
+    unet.load_state_dict(sds["u"], device=device)
+    cn.load_state_dict(sds["c"], device=device)
+    inp = {k: v.to(device) for k, v in fullsize_inputs().items()}
+    T = c["T"]
+    wrap = StreamingWrapper(unet, cn, c["Tc"])
+    out = wrap.forward(inp["x"], inp["t"], {k: inp[k] for k in ("concat", "crossattn", "vector")}, batch_size=2, num_video_frames=T,
+                       image_only_indicator=torch.zeros(2, T, device=device), ctrl_frames=inp["ctrl_frames"])
+    torch.cuda.synchronize()
+    res = frame_errors(out, gold["out"])
+    del unet, cn, wrap
+    torch.cuda.empty_cache()
+    return res
+
+
+def decoder_fullsize(dtype, device="cuda"):
+    from oracle.cases import fullsize_pixel_subset, fullsize_vae_inputs
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import VideoDecoder
+    torch.set_grad_enabled(False)
+    ops.set_element_dtype(DT[dtype])
+    gold = torch.load(os.path.join(GOLD, "vae_fullsize.pt"))
+    dec = VideoDecoder()
+    dec.load_state_dict(init_by_name(dec.spec(), seed=35), device=device)
+    z = fullsize_vae_inputs()["z"].to(device)
+    out = dec.forward(z, timesteps=z.shape[0])
+    torch.cuda.synchronize()
+    idx = fullsize_pixel_subset(out.shape[-2] * out.shape[-1])
+    sub = out.float().flatten(2)[:, :, idx.to(device)]
+    res = frame_errors(sub, gold["out_subset"])
+    del dec
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="both")
+    ap.add_argument("--which", default="both")
+    a = ap.parse_args()
+    sds = {}
+    for name in ("fp16", "bf16"):
+        if a.dtype not in ("both", name):
+            continue
+        if a.which in ("both", "vae"):
+            r = decoder_fullsize(name)
+            print(f"[full-size VideoDecoder 2 frames @576x1024 vs reference, {name}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | "
+                  f"rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | corr {r['corr']:.7f}", flush=True)
+        if a.which in ("both", "wrapper"):
+            r = wrapper_fullsize(name, sds=sds)
+            print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, {name}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | "
+                  f"rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | corr {r['corr']:.7f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
