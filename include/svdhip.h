@@ -159,6 +159,15 @@ int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t 
 int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
                         int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
                         const float* gamma, const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream);
+/* Sequence-parallel form of the 5-D statistics (time_stack GroupNorms models/diffusion/video_model.py:75-80 and the CAM merger's
+ * norm models/cam/conditioning.py:57-59 pool over ALL frames and pixels of a batch element): when the frames / pixels of a batch element
+ * are sharded over the ranks of a process group, every rank reduces ITS rows to sums[frames/frames_per_stat][groups][2] = (sum, sum of
+ * squares) in double, the ranks add them (RCCL all-reduce of 2 x 32 x batch doubles), and svd_groupnorm_stats_from_sums forms
+ * (mean, rstd) with the GLOBAL element count -- svd_groupnorm_apply then runs unchanged on the local rows. */
+int svd_groupnorm_sums(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels, int32_t groups,
+                       int32_t frames_per_stat, float* partial, double* sums, int32_t dtype, svd_stream_t stream);
+int svd_groupnorm_stats_from_sums(const double* sums, int32_t nstat, int32_t groups, double count, float eps, float* stats,
+                                  svd_stream_t stream);
 
 /* LayerNorm over channels per token (eps 1e-5), optional per-frame vector added first (x + vec[frame]) with the
  * sum also written to Xsum (used for "x_mix = x + time_pos_embed" video_attention.py:318-321), optional SiLU

@@ -92,6 +92,35 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// sequence-parallel form of the 5-D statistics: the same fixed-order reduction of the partials, but the (sum, sum of squares) pair is
+// written out in double so that the ranks of a sequence-parallel group can add their shares (RCCL all-reduce) before the statistics
+// are formed by gn_stats_from_sums_kernel with the GLOBAL element count.
+__global__ __launch_bounds__(64) void gn_sums_kernel(const float* __restrict__ partial, int groups, int frames_per_stat, int nchunk,
+                                                     double* __restrict__ sums) {
+    const int i = blockIdx.x;
+    const int sb = i / groups, g = i - sb * groups;
+    const int n = frames_per_stat * nchunk;
+    const float* base = partial + ((int64_t)sb * n * groups + g) * 2;
+    double a = 0.0, b = 0.0;
+    for (int e = threadIdx.x; e < n; e += 64) {
+        const float2 v = *(const float2*)(base + (int64_t)e * groups * 2);
+        a += v.x; b += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (threadIdx.x == 0) { sums[2 * i + 0] = a; sums[2 * i + 1] = b; }
+}
+
+__global__ void gn_stats_from_sums_kernel(const double* __restrict__ sums, int n, double count, float eps, float* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mean = sums[2 * i] / count;
+    double var = sums[2 * i + 1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i + 0] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 template <class E>
 __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int pix,
                                 int channels, int groups, int frames_per_stat, int nchunk, const float* __restrict__ stats,
@@ -258,6 +287,32 @@ extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frame
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(nstat * groups), dim3(64), 0, (hipStream_t)stream, partial,
                        nstat, groups, frames_per_stat, nchunk, count, eps, stats);
     SVD_CHECK_LAUNCH("gn_finalize");
+    return SVD_OK;
+}
+
+extern "C" int svd_groupnorm_sums(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels, int32_t groups,
+                                  int32_t frames_per_stat, float* partial, double* sums, int32_t dtype, svd_stream_t stream) {
+    if (!X || !partial || !sums || frames <= 0 || pix <= 0 || channels <= 0) return SVD_EINVAL;
+    if (groups <= 0 || groups > 32 || channels % groups || channels % 8 || ldx % 8 || channels > 8192) return SVD_EINVAL;
+    if (frames_per_stat <= 0 || frames % frames_per_stat || frames > 65535) return SVD_EINVAL;
+    if (((uintptr_t)X & 15) || ((uintptr_t)sums & 7)) return SVD_EINVAL;
+    const int nchunk = gn_nchunk(frames, pix);
+    const int bs = gn_block(channels);
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_stats_partial_kernel<E>, dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
+                                                 (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
+    SVD_CHECK_LAUNCH("gn_stats_partial");
+    hipLaunchKernelGGL(gn_sums_kernel, dim3((frames / frames_per_stat) * groups), dim3(64), 0, (hipStream_t)stream, partial, groups, frames_per_stat,
+                       nchunk, sums);
+    SVD_CHECK_LAUNCH("gn_sums");
+    return SVD_OK;
+}
+
+extern "C" int svd_groupnorm_stats_from_sums(const double* sums, int32_t nstat, int32_t groups, double count, float eps, float* stats,
+                                             svd_stream_t stream) {
+    if (!sums || !stats || nstat <= 0 || groups <= 0 || groups > 32 || !(count > 0.0)) return SVD_EINVAL;
+    const int n = nstat * groups;
+    hipLaunchKernelGGL(gn_stats_from_sums_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, n, count, eps, stats);
+    SVD_CHECK_LAUNCH("gn_stats_from_sums");
     return SVD_OK;
 }
 

@@ -13,15 +13,15 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""), "libsvdhip.so"))   # probe: developer build with a reduced tile table
+LIB_PATH = os.path.join(_HERE, {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""), os.environ.get("SVD_LIB_FILE", "libsvdhip.so")))   # probe / SVD_LIB_FILE: developer builds (reduced tile table, timing probes)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
     "svd_abi_version", "svd_last_error", "svd_gemm", "svd_gemm_num_configs", "svd_gemm_config_info", "svd_gemm_pick_config", "svd_gemm_config_valid",
     "svd_attn_spatial_d64", "svd_attn_temporal_d64", "svd_softmax_rows",
-    "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_layernorm",
+    "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_groupnorm_sums", "svd_groupnorm_stats_from_sums", "svd_layernorm",
     "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32",
     "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
     "svd_attn_cross_d64", "svd_adaptive_avgpool_tokens", "svd_i2v_image_temporal_encoder", "svd_ddim_cfg_step", "svd_frames_to_uint8", "svd_gelu_rows",
@@ -91,6 +91,8 @@ def _load():
     lib.svd_softmax_rows.argtypes = [vp, i64, vp, i64, i64, i32, f32, i32, vp]
     lib.svd_groupnorm_stats.argtypes = [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]
     lib.svd_groupnorm_apply.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp]
+    lib.svd_groupnorm_sums.argtypes = [vp, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.svd_groupnorm_stats_from_sums.argtypes = [vp, i32, i32, C.c_double, f32, vp, vp]
     lib.svd_layernorm.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, f32, vp, i32, i32, vp, i64, i32, i32, vp]
     lib.svd_nchw_to_tokens.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.svd_tokens_to_nchw.argtypes = [vp, i32, i64, vp, i32, i32, i32, vp]
@@ -125,7 +127,13 @@ def _load():
 lib = _load()
 
 
+_DEBUG_SYNC = bool(os.environ.get("SVD_DEBUG_SYNC"))    # developer aid: device-synchronise after every launch (a faulting kernel then
+                                                          # aborts inside ITS OWN launcher call: the Python traceback names it)
+
+
 def check(rc, what):
+    if _DEBUG_SYNC and rc == 0:
+        torch.cuda.synchronize()
     if rc != 0:
         msg = lib.svd_last_error().decode() if rc == -2 else "invalid argument (SVD_EINVAL)"
         raise SvdHipError(f"{what} failed with code {rc}: {msg}")

@@ -218,6 +218,35 @@ def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False
     return out
 
 
+def groupnorm_sums(x, frames, pix, frames_per_stat, groups=32):
+    """This rank's share of the GroupNorm statistics: [frames/frames_per_stat, groups, 2] float64 (sum, sum of squares) over its rows;
+    the ranks of a sequence-parallel group add them (parallel.SeqParallel.allreduce_sums) before groupnorm_apply_sums."""
+    rows, ld = _rows_ld(x)
+    Cc = x.shape[1]
+    assert rows == frames * pix and frames % frames_per_stat == 0
+    partial, _ = _gn_workspace(x.device, frames, Cc, frames // frames_per_stat, groups)
+    sums = torch.empty((frames // frames_per_stat, groups, 2), dtype=torch.float64, device=x.device)
+    check(_lib.svd_groupnorm_sums(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, _p(partial), _p(sums), _dt(x), _stream()),
+          "svd_groupnorm_sums")
+    return sums
+
+
+def groupnorm_apply_sums(x, frames, pix, gamma, beta, eps, sums, count, *, frames_per_stat=1, silu=False, groups=32, out=None):
+    """GroupNorm (+SiLU) of the local rows with statistics formed from (all-reduced) sums over `count` elements per (batch, group)."""
+    rows, ld = _rows_ld(x)
+    Cc = x.shape[1]
+    nstat = frames // frames_per_stat
+    assert sums.dtype == torch.float64 and sums.is_contiguous() and tuple(sums.shape) == (nstat, groups, 2)
+    _, stats = _gn_workspace(x.device, frames, Cc, nstat, groups)
+    check(_lib.svd_groupnorm_stats_from_sums(_p(sums), nstat, groups, float(count), float(eps), _p(stats), _stream()),
+          "svd_groupnorm_stats_from_sums")
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.svd_groupnorm_apply(_p(x), ld, _p(out), out.stride(0), frames, pix, Cc, groups, frames_per_stat,
+                                   _p(stats), _p(gamma), _p(beta), int(silu), _dt(x), _stream()), "svd_groupnorm_apply")
+    return out
+
+
 def layernorm(x, gamma, beta, *, eps=1e-5, addvec=None, rows_per_vec=0, want_sum=False, silu=False, out=None):
     rows, ld = _rows_ld(x)
     Cc = x.shape[1]

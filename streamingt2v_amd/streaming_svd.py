@@ -32,13 +32,35 @@ class StreamingSVD:
 
     @torch.no_grad()
     def decode_first_stage(self, z, clamp=False):
+        """z / 0.18215, frames decoded in groups of 8 (4 with memopt) exactly like the reference (the temporal convolutions zero-pad at the
+        group boundaries, so the grouping is part of the result).  The groups are independent: when the decoder carries a process group
+        (`first_stage_model.decode_group`, set by parallel.JobPlan.attach) group n is decoded by rank n % world and broadcast -- every rank
+        ends up with all frames (the next chunk's control frames), bit-identical to the single-process decode."""
         z = z * (1.0 / self.scale_factor)
         n_samples = min(z.shape[0], 4 if self.use_memopt else 8)
-        outs = []
-        for n in range(math.ceil(z.shape[0] / n_samples)):
+        n_groups = math.ceil(z.shape[0] / n_samples)
+        group = getattr(self.first_stage_model, "decode_group", None)
+        if group is None:
+            outs = []
+            for n in range(n_groups):
+                zc = z[n * n_samples:(n + 1) * n_samples]
+                outs.append(self.first_stage_model.decode(zc, timesteps=len(zc), clamp=clamp))
+            return torch.cat(outs, dim=0)
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        out = None
+        mine = {}
+        for n in range(rank, n_groups, world):
             zc = z[n * n_samples:(n + 1) * n_samples]
-            outs.append(self.first_stage_model.decode(zc, timesteps=len(zc), clamp=clamp))
-        return torch.cat(outs, dim=0)
+            mine[n] = self.first_stage_model.decode(zc, timesteps=len(zc), clamp=clamp)
+        shape = self.first_stage_model.output_shape(z) if not mine else (z.shape[0],) + tuple(next(iter(mine.values())).shape[1:])
+        out = torch.empty(shape, dtype=torch.float32, device=z.device)
+        for n in range(n_groups):
+            part = out[n * n_samples:(n + 1) * n_samples]
+            if n in mine:
+                part.copy_(mine[n])
+            dist.broadcast(part, src=dist.get_global_rank(group, n % world), group=group)
+        return out
 
     @torch.no_grad()
     def _generate_conditional_output(self, c, uc, ctrl_frames, noise, num_steps=None):

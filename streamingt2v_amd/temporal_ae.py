@@ -206,11 +206,18 @@ class AutoencodingEngineDecoder:
     """The slice of AutoencodingEngine the hot path touches: ``decode(z, timesteps=n)`` and ``.decoder``
     (code/models/svd/sgm/models/autoencoder.py:210-212, diffusion_trainer/streaming_svd.py:138-146)."""
 
+    decode_group = None      # torch.distributed group over which StreamingSVD.decode_first_stage shards the independent frame groups
+
     def __init__(self, decoder):
         self.decoder = decoder
 
     def decode(self, z, **kwargs):
         return self.decoder.forward(z, **kwargs)
+
+    @staticmethod
+    def output_shape(z):
+        """decoded frames of latents z [n, 4, h, w]: [n, 3, 8h, 8w]."""
+        return (z.shape[0], 3, 8 * z.shape[2], 8 * z.shape[3])
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

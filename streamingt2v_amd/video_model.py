@@ -78,6 +78,13 @@ def _sigmoid(x):
     return 1.0 / (1.0 + math.exp(-float(x)))
 
 
+def _gn_pooled(x, frames, pix, w, b, eps, frames_per_stat, count, sp, silu):
+    """GroupNorm whose statistics pool over rows that are sharded over the ranks of `sp` (the 5-D norms of time_stack and of the CAM
+    merger): local (sum, sum of squares) -> all-reduce -> statistics with the GLOBAL element count -> apply on the local rows."""
+    sums = sp.allreduce_sums(ops.groupnorm_sums(x, frames, pix, frames_per_stat))
+    return ops.groupnorm_apply_sums(x, frames, pix, w, b, eps, sums, count, frames_per_stat=frames_per_stat, silu=silu)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class VideoResBlock:
     """ResBlock (2-D) -> time_stack ResBlock (3,1,1) -> AlphaBlender.  video_model.py:66-85, openaimodel.py:328-354."""
@@ -121,24 +128,41 @@ class VideoResBlock:
         self.tw2, self.tb2 = _dev_bf16(pack_tconv3(g(t + "out_layers.3.weight")), dev), _dev_f32(g(t + "out_layers.3.bias"), dev)
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))   # image_only_indicator == 0 (util.py:341-357)
 
-    def forward(self, x, emb_silu, F, T, H, W):
+    def forward(self, x, emb_silu, F, T, H, W, sp=None, emb_full=None):
+        """x [F*H*W, C]: the frames this rank holds (all B*T of them without sequence parallelism; then emb_silu is also the
+        embedding of all frames).  With `sp` (parallel.SeqParallel): emb_silu = embedding rows of the LOCAL frames (2-D part),
+        emb_full = rows of all B*T frames (the time_stack runs in the pixel layout, where every rank sees all frames)."""
         pix = H * W
         cv_in = dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F)
         cv = dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F)
-        tv = dict(cin=self.cout, T=T, pix=pix)
         h = ops.groupnorm(x, F, pix, self.n1w, self.n1b, 1e-5, silu=True)
         e = ops.gemm(emb_silu, self.we, bias=self.be, out_f32=True)
         h = ops.gemm(h, self.w1, bias=self.b1, rowvec=e, rows_per_vec=pix, conv=cv_in)
         h = ops.groupnorm(h, F, pix, self.n2w, self.n2b, 1e-5, silu=True)
         skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
         hs = ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=cv)
-        # time_stack: 5-D GroupNorm statistics pool over the T frames of a batch element (video_model.py:75-80)
-        g = ops.groupnorm(hs, F, pix, self.tn1w, self.tn1b, 1e-5, frames_per_stat=T, silu=True)
-        et = ops.gemm(emb_silu, self.twe, bias=self.tbe, out_f32=True)
-        g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pix, temporal=tv)
-        g = ops.groupnorm(g, F, pix, self.tn2w, self.tn2b, 1e-5, frames_per_stat=T, silu=True)
-        # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip)
-        return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(self.alpha, hs), temporal=tv)
+        if sp is None:
+            # time_stack: 5-D GroupNorm statistics pool over the T frames of a batch element (video_model.py:75-80)
+            tv = dict(cin=self.cout, T=T, pix=pix)
+            g = ops.groupnorm(hs, F, pix, self.tn1w, self.tn1b, 1e-5, frames_per_stat=T, silu=True)
+            et = ops.gemm(emb_silu, self.twe, bias=self.tbe, out_f32=True)
+            g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pix, temporal=tv)
+            g = ops.groupnorm(g, F, pix, self.tn2w, self.tn2b, 1e-5, frames_per_stat=T, silu=True)
+            # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip)
+            return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(self.alpha, hs), temporal=tv)
+        # sequence parallel: the whole time_stack in the PIXEL layout (all T frames of this rank's pixel range); its two norms pool
+        # over every frame and pixel -> all-reduce of the sums
+        B = emb_full.shape[0] // T
+        pl = sp.pix_local(pix)
+        hp = sp.to_pixels(hs, B, T, pix)
+        tv = dict(cin=self.cout, T=T, pix=pl)
+        cnt = float(T) * pix * (self.cout // 32)
+        g = _gn_pooled(hp, B * T, pl, self.tn1w, self.tn1b, 1e-5, T, cnt, sp, True)
+        et = ops.gemm(emb_full, self.twe, bias=self.tbe, out_f32=True)
+        g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pl, temporal=tv)
+        g = _gn_pooled(g, B * T, pl, self.tn2w, self.tn2b, 1e-5, T, cnt, sp, True)
+        out = ops.gemm(g, self.tw2, bias=self.tb2, residual=hp, blend=(self.alpha, hp), temporal=tv)
+        return sp.to_frames(out, B, T, pix)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -257,10 +281,11 @@ class SpatialVideoTransformer:
             self._temb[key] = e
         return e
 
-    def forward(self, x, ctx, tctx, F, T, H, W):
-        """x [F*H*W, C]; ctx [F, ctx_dim] bf16 (per-frame CLIP token); tctx [F//T, ctx_dim] (= context[::T])."""
+    def forward(self, x, ctx, tctx, F, T, H, W, sp=None):
+        """x [F*H*W, C]; ctx [F, ctx_dim] bf16 (per-frame CLIP token); tctx [B, ctx_dim] (= context[::T]).  With `sp`
+        (parallel.SeqParallel) x / ctx hold this rank's frames; the temporal block runs in the pixel layout."""
         c, heads, pix = self.c, self.heads, H * W
-        M, B = F * pix, F // T
+        M, B = F * pix, tctx.shape[0]
         h = ops.groupnorm(x, F, pix, self.nw, self.nb, 1e-6, silu=False)
         h = ops.gemm(h, self.wpi, bias=self.bpi)
         # ---- spatial BasicTransformerBlock (attention.py:567-593) ----
@@ -276,18 +301,22 @@ class SpatialVideoTransformer:
         g = ops.gemm(n3, self.s_wf1, bias=self.s_bf1, geglu=True)
         h = ops.gemm(g, self.s_wf2, bias=self.s_bf2, residual=h)          # x_spatial
         # ---- temporal VideoTransformerBlock on the same token layout (video_attention.py:125-168) ----
-        nin, xm = ops.layernorm(h, *self.t_ln["norm_in"], addvec=self._time_emb(F, T), rows_per_vec=pix, want_sum=True)
+        # rows (b, t, pixel) with pt pixels per frame: all of them, or this rank's pixel range of ALL T frames (one all-to-all in)
+        ht, pt = (h, pix) if sp is None else (sp.to_pixels(h, B, T, pix), sp.pix_local(pix))
+        nin, xm = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=self._time_emb(B * T, T), rows_per_vec=pt, want_sum=True)
         g = ops.gemm(nin, self.t_wi1, bias=self.t_bi1, geglu=True)
         xm = ops.gemm(g, self.t_wi2, bias=self.t_bi2, residual=xm)
         n1 = ops.layernorm(xm, *self.t_ln["norm1"])
         qkv = ops.gemm(n1, self.t_wqkv)
-        at = torch.empty((M, c), dtype=x.dtype, device=x.device)
-        ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pix, heads)
+        at = torch.empty((B * T * pt, c), dtype=x.dtype, device=x.device)
+        ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pt, heads)
         v2t = ops.gemm(ops.gemm(tctx, self.t_wv2), self.t_wo2, bias=self.t_bo2, out_f32=True)    # [B, C]
-        xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pix, residual=xm)
+        xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm)
         n3 = ops.layernorm(xm, *self.t_ln["norm3"])
         g = ops.gemm(n3, self.t_wf1, bias=self.t_bf1, geglu=True)
-        xb = ops.gemm(g, self.t_wf2, bias=self.t_bf2, residual=xm, blend=(self.alpha, h))     # AlphaBlender
+        xb = ops.gemm(g, self.t_wf2, bias=self.t_bf2, residual=xm, blend=(self.alpha, ht))     # AlphaBlender
+        if sp is not None:
+            xb = sp.to_frames(xb, B, T, pix)                                                    # one all-to-all out
         return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x)
 
 
@@ -316,15 +345,26 @@ class ConditionalModel:
         self.wkv = _dev_bf16(torch.cat([g("attention.to_k.weight"), g("attention.to_v.weight")], 0), dev)
         self.wo, self.bo = _dev_bf16(g("attention.to_out.0.weight"), dev), _dev_f32(g("attention.to_out.0.bias"), dev)
 
-    def forward(self, sample, cond, F, T, Tc, H, W):
+    def forward(self, sample, cond, F, T, Tc, H, W, sp=None):
+        """sample [F*pix, C] (F = B * frames held by this rank), cond [B*Tc(local)*pix, C] ControlNet features.  With `sp` the queries are
+        this rank's frames, the 7 conditioning frames' K / V are all-gathered (they are sharded like the ControlNet that made them), and
+        the 5-D GroupNorm sums are all-reduced."""
         c, pix = self.c, H * W
-        B = F // T
-        hn = ops.groupnorm(sample, F, pix, self.nw, self.nb, 1e-6, frames_per_stat=T, silu=False)
+        if sp is None:
+            B = F // T
+            hn = ops.groupnorm(sample, F, pix, self.nw, self.nb, 1e-6, frames_per_stat=T, silu=False)
+            Tq = T
+        else:
+            Tq = sp.frame_counts(T)[sp.rank]
+            B = F // Tq
+            hn = _gn_pooled(sample, F, pix, self.nw, self.nb, 1e-6, Tq, float(T) * pix * (c // 32), sp, False)
         hn = ops.gemm(hn, self.wpi, bias=self.bpi)
         q = ops.gemm(hn, self.wq)
         kv = ops.gemm(cond, self.wkv)
+        if sp is not None:
+            kv = sp.gather_frames(kv, B, Tc, pix)
         a = torch.empty((F * pix, c), dtype=sample.dtype, device=sample.device)
-        ops.attn_temporal(q, kv[:, :c], kv[:, c:], a, B, T, Tc, pix, self.heads)
+        ops.attn_temporal(q, kv[:, :c], kv[:, c:], a, B, Tq, Tc, pix, self.heads)
         a = ops.gemm(a, self.wo, bias=self.bo)
         # dropout(p=.25) on the non-conditional frames is identity in eval mode (conditioning.py:74-75)
         return ops.gemm(a, self.wpo, bias=self.bpo, residual=sample)
@@ -439,15 +479,25 @@ class _EncoderBase:
         return ops.to_bf16(emb, silu=True)                          # every emb_layers starts with SiLU
 
     @staticmethod
-    def _run(layers, h, emb_silu, ctx, tctx, F, T, H, W):
+    def _run(layers, h, emb_silu, ctx, tctx, F, T, H, W, sp=None, emb_full=None):
         for m in layers:
             if isinstance(m, VideoResBlock):
-                h = m.forward(h, emb_silu, F, T, H, W)
+                h = m.forward(h, emb_silu, F, T, H, W, sp=sp, emb_full=emb_full)
             elif isinstance(m, SpatialVideoTransformer):
-                h = m.forward(h, ctx, tctx, F, T, H, W)
+                h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp)
             else:
                 h, H, W = m.forward(h, F, H, W)
         return h, H, W
+
+    def _local_conditioning(self, timesteps, context, y, T, sp):
+        """(emb of this rank's frames, emb of all frames, per-frame context of this rank's frames, per-video context, local frame count).
+        timesteps / context / y always describe ALL B*T frames (they are tiny); `sp` selects this rank's rows."""
+        emb_full = self._embed(timesteps, y)
+        ctx, tctx = self._contexts(context, T)
+        if sp is None:
+            return emb_full, emb_full, ctx, tctx, timesteps.numel()
+        B = timesteps.numel() // T
+        return sp.take_frames(emb_full, B, T), emb_full, sp.take_frames(ctx, B, T), tctx, B * sp.frame_counts(T)[sp.rank]
 
     @staticmethod
     def _contexts(context, T):
@@ -526,33 +576,37 @@ class VideoUNet(_EncoderBase):
         return self
 
     def forward_tokens(self, x_tok, timesteps, context, y, T, H, W, hs_control_input=None, hs_control_mid=None,
-                       num_conditional_frames=None):
-        """x_tok [F*H*W, 32] bf16 (8 latent channels zero-padded to 32).  Returns [F*H*W, 4] fp32 tokens."""
-        F = timesteps.numel()
-        emb_silu = self._embed(timesteps, y)
-        ctx, tctx = self._contexts(context, T)
+                       num_conditional_frames=None, sp=None):
+        """x_tok [F*H*W, 32] bf16 (8 latent channels zero-padded to 32).  Returns [B*T*H*W, 4] fp32 tokens of ALL frames.
+        With `sp` (parallel.SeqParallel) x_tok and the hs_control_* tensors hold THIS RANK'S frames only (timesteps / context / y still
+        describe all B*T frames); the network output is all-gathered over the group before it is returned."""
+        emb_silu, emb_full, ctx, tctx, F = self._local_conditioning(timesteps, context, y, T, sp)
+        assert x_tok.shape[0] == F * H * W
+        kw = dict(sp=sp, emb_full=emb_full)
         hs = []
         h = x_tok
         for blk in self.input_blocks:
-            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W)
+            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, **kw)
             hs.append((h, H, W))
         if hs_control_input is not None:
             # CAM: merge ControlNet features into every skip tensor (video_model.py:582-591)
             assert len(hs) == len(hs_control_input) == len(self.cross_attention_merger_input_blocks)
             Tc = num_conditional_frames
-            hs = [(mg.forward(hh, hc, F, T, Tc, Hh, Wh), Hh, Wh)
+            hs = [(mg.forward(hh, hc, F, T, Tc, Hh, Wh, sp=sp), Hh, Wh)
                   for (hh, Hh, Wh), hc, mg in zip(hs, hs_control_input, self.cross_attention_merger_input_blocks)]
         # middle_block consumes the UN-merged encoder output (video_model.py:593-600)
-        h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W)
+        h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W, **kw)
         if hs_control_mid is not None:
-            h = self.cross_attention_merger_mid_block.forward(h, hs_control_mid, F, T, num_conditional_frames, H, W)
+            h = self.cross_attention_merger_mid_block.forward(h, hs_control_mid, F, T, num_conditional_frames, H, W, sp=sp)
         for blk in self.output_blocks:
             skip, Hs, Ws = hs.pop()
             assert (Hs, Ws) == (H, W)
             h = ops.concat_channels(h, skip)
-            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W)
+            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, **kw)
         h = ops.groupnorm(h, F, H * W, self.ow, self.ob, 1e-5, silu=True)
         out, _, _ = self.out_conv.forward(h, F, H, W, out_f32=True)
+        if sp is not None:
+            out = sp.gather_frames(out, timesteps.numel() // T, T, H * W)
         return out
 
     def forward(self, x, timesteps, context=None, y=None, time_context=None, num_video_frames=None,
@@ -660,19 +714,22 @@ class ControlNet(_EncoderBase):
             self._cond_cache = c = (controlnet_cond, controlnet_cond._version, self.controlnet_cond_embedding.forward(controlnet_cond)[0])
         return c[2]
 
-    def forward_tokens(self, x_tok, timesteps, controlnet_cond, context, y, T, H, W):
-        F = timesteps.numel()
-        emb_silu = self._embed(timesteps, y)
-        ctx, tctx = self._contexts(context, T)
+    def forward_tokens(self, x_tok, timesteps, controlnet_cond, context, y, T, H, W, sp=None):
+        """With `sp`: x_tok and controlnet_cond hold this rank's share of the B*T conditioning frames; the returned features do too."""
+        emb_silu, emb_full, ctx, tctx, F = self._local_conditioning(timesteps, context, y, T, sp)
+        assert x_tok.shape[0] == F * H * W
         cond = self.embed_condition(controlnet_cond)
         hs = []
         h = x_tok
         for i, blk in enumerate(self.input_blocks):
-            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W)
+            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, sp=sp, emb_full=emb_full)
             if i == 0:
+                if cond.shape[0] != h.shape[0]:
+                    raise ValueError(f"controlnet_cond embeds to {cond.shape[0]} tokens but the latent batch has {h.shape[0]}: the control "
+                                     f"frames must be {controlnet_cond.shape[0]} x 3 x {8 * H} x {8 * W} pixels (8x the latent, controlnet.py:75-102)")
                 h = ops.add_rows(h, cond)          # Merger 'addition', frame_expansion none (controlnet.py:23-48)
             hs.append(h)
-        h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W)
+        h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W, sp=sp, emb_full=emb_full)
         return hs, h
 
     def forward(self, x, timesteps, controlnet_cond, context=None, y=None, time_context=None, num_video_frames=None,

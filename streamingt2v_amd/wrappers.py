@@ -25,14 +25,17 @@ class StreamingWrapper:
         return self
 
     # ---- shared core on token tensors ------------------------------------------------------------------------
+    sp = None      # parallel.SeqParallel: the forward runs frame <-> pixel sequence-parallel over its group (set by parallel.JobPlan.attach)
+
     def _run(self, x_tok, t, context, y, batch_size, T, H, W, ctrl_frames):
+        """x_tok [B*T*pix, 32] tokens of ALL frames (cheap); with self.sp every rank slices its frames out of them, runs its share of the
+        ControlNet and of the UNet, and the UNet all-gathers the output: the result is the same [B*T*pix, 4] fp32 on every rank."""
         Tc = self.num_frame_conditioning
+        sp, pix = self.sp, H * W
         hs_c = mid_c = None
         # no control frames (first chunk: plain SVD, video_model.py:582,603 with hs_control_* = None) -> UNet only
         if self.diffusion_model.controlnet_mode and ctrl_frames is not None:
             # ControlNet sees the first Tc frames of each CFG half (wrappers.py:28-42) ...
-            pix = H * W
-
             def reduce_rows(v, per):           # "(B F) ... -> B F ..." [:, :Tc]
                 v = v.reshape(batch_size, T * per, *v.shape[1:])[:, :Tc * per]
                 return v.reshape(batch_size * Tc * per, *v.shape[2:]).contiguous()
@@ -45,17 +48,25 @@ class StreamingWrapper:
             # "(2 B) F ..." in the reference (B = 1 video, CFG batch 2); one copy per batch element here so that a rank
             # holding a single CFG half (parallel.CfgPairExchange) repeats once
             cond = self._cond_cached(ctrl_frames, batch_size)
-            hs_c, mid_c = self.controlnet.forward_tokens(x_ctrl, t_ctrl, cond, ctx_ctrl, y_ctrl, Tc, H, W)
-        return self.diffusion_model.forward_tokens(x_tok, t, context, y, T, H, W, hs_c, mid_c, Tc)
+            if sp is not None:
+                assert sp.size <= Tc, "sequence parallelism shards the Tc conditioning frames of the ControlNet: degree <= Tc"
+                x_ctrl = sp.take_frames(x_ctrl, batch_size, Tc, pix)
+            hs_c, mid_c = self.controlnet.forward_tokens(x_ctrl, t_ctrl, cond, ctx_ctrl, y_ctrl, Tc, H, W, sp=sp)
+        if sp is not None:
+            x_tok = sp.take_frames(x_tok, batch_size, T, pix)
+        return self.diffusion_model.forward_tokens(x_tok, t, context, y, T, H, W, hs_c, mid_c, Tc, sp=sp)
 
     def _cond_cached(self, ctrl_frames, batch_size):
         # ONE repeated fp32 tensor per ctrl_frames OBJECT (built on a miss only) so ControlNet.embed_condition can recognise it.  The
         # cache holds a reference to ctrl_frames itself and compares identity + in-place version: a (data_ptr, shape, version) key can
         # collide once the tensor is freed and the caching allocator hands the same address to the next video's control frames.
+        # With sequence parallelism the cached tensor holds this rank's share of the conditioning frames.
         held = getattr(self, "_cond_src", None)
-        if held is None or held[0] is not ctrl_frames or held[1] != ctrl_frames._version or held[2] != batch_size:
+        if held is None or held[0] is not ctrl_frames or held[1] != ctrl_frames._version or held[2] != batch_size or held[3] is not self.sp:
             cond = ctrl_frames.repeat(batch_size // ctrl_frames.shape[0], *([1] * (ctrl_frames.dim() - 1))).flatten(0, 1)
-            self._cond_src = (ctrl_frames, ctrl_frames._version, batch_size)
+            if self.sp is not None:
+                cond = self.sp.take_frames(cond, batch_size, self.num_frame_conditioning)
+            self._cond_src = (ctrl_frames, ctrl_frames._version, batch_size, self.sp)
             self._cond_val = cond.float().contiguous()
         return self._cond_val
 

@@ -1,0 +1,211 @@
+"""Plain-torch fp32 statements of the `streamingt2v_amd.ops` launchers that the StreamingSVD denoiser path uses (video_model.py,
+wrappers.py, sampling.py) -- TEST INFRASTRUCTURE, never imported by the product.
+
+`install(monkeypatch)` routes streamingt2v_amd.ops through them with fp32 "elements", so that the HOST logic of the networks (layouts,
+weight packing, epilogue bookkeeping, ControlNet slicing, CAM wiring, the sequence-parallel layout changes and collectives) runs on CPU:
+  * tests/test_host_svd_cpu.py  : host logic vs the CPU oracle (oracle/svd_oracle.py) on the tiny configuration;
+  * tests/test_distributed_cpu.py: the sequence-parallel forward on gloo ranks == the single-process forward.
+Each function follows the argument contract documented in streamingt2v_amd/ops.py / include/svdhip.h.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _geglu_unpack(y):
+    """columns interleaved (value | gate) in blocks of 32 (video_model.pack_geglu) -> value * gelu_erf(gate)."""
+    M, N = y.shape
+    y = y.view(M, N // 64, 2, 32)
+    return (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(M, N // 2)
+
+
+def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=None, geglu=False, silu=False, out=None, out_f32=False,
+         conv=None, temporal=None, trans_out=None, n_out=None, tile_cfg=0, k=None):
+    a32, w32 = a.float(), w.float()
+    N = w.shape[0]
+    K = k if k is not None else w.shape[1]
+    w32 = w32[:, :K]
+    if conv is not None:
+        n, cin, hin, win = conv["frames"], conv["cin"], conv["hin"], conv["win"]
+        assert a.shape[0] == n * hin * win and K == 9 * cin
+        x = a32[:, :cin].reshape(n, hin, win, cin).permute(0, 3, 1, 2)
+        if conv.get("ups", 0):
+            x = F.interpolate(x, size=(conv["hout"], conv["wout"]), mode="nearest")
+        wk = w32.view(N, 3, 3, cin).permute(0, 3, 1, 2)
+        stride = conv.get("stride", 1)
+        if conv.get("pad_mode", 0):
+            y = F.conv2d(F.pad(x, (0, 1, 0, 1)), wk, None, stride, 0)
+        else:
+            y = F.conv2d(x, wk, None, stride, 1)
+        assert tuple(y.shape[2:]) == (conv["hout"], conv["wout"]), (y.shape, conv)
+        y = y.permute(0, 2, 3, 1).reshape(-1, N)
+    elif temporal is not None:
+        cin, T, pix = temporal["cin"], temporal["T"], temporal["pix"]
+        M = a.shape[0]
+        B = M // (T * pix)
+        x = a32[:, :cin].reshape(B, T, pix, cin).permute(0, 3, 1, 2)[..., None]          # b c t p 1
+        wk = w32.view(N, 3, cin).permute(0, 2, 1)[..., None, None]
+        y = F.conv3d(x, wk, None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        y = a32[:, :K] @ w32.t()
+    M = y.shape[0]
+    if bias is not None:
+        y = y + bias[:N]
+    if trans_out is not None:
+        o = trans_out["out"]
+        tpf = trans_out["tok_per_frame"]
+        o[:, :, :tpf] = y.view(M // tpf, tpf, N).transpose(1, 2).to(o.dtype)
+        return o
+    if geglu:
+        y = _geglu_unpack(y)
+    if rowvec is not None:
+        idx = torch.arange(M, device=y.device) // rows_per_vec
+        y = y + rowvec[idx][:, : y.shape[1]]
+    if residual is not None:
+        y = y + residual.float()
+    if blend is not None:
+        alpha, S = blend
+        y = alpha * S.float() + (1.0 - alpha) * y
+    if silu:
+        y = F.silu(y)
+    if n_out is not None:
+        y = y[:, :n_out]
+    if out is not None:
+        out.copy_(y.to(out.dtype))
+        return out
+    return y if out_f32 else y.to(a.dtype)
+
+
+def attn_spatial(q, k, vt, out, frames, n_tok, heads):
+    C = heads * 64
+    qh = q.float()[:, :C].reshape(frames, n_tok, heads, 64).transpose(1, 2)
+    kh = k.float()[:, :C].reshape(frames, n_tok, heads, 64).transpose(1, 2)
+    vh = vt.float()[:, :, :n_tok].reshape(frames, heads, 64, n_tok).transpose(2, 3)
+    o = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(frames * n_tok, C)
+    out.copy_(o.to(out.dtype))
+    return out
+
+
+def attn_temporal(q, k, v, out, batch, tq, tk, n_pix, heads):
+    C = heads * 64
+
+    def bpthd(t, T):      # rows (b t p), cols (h d) -> (b p) h t d
+        return t.float()[:, :C].reshape(batch, T, n_pix, heads, 64).permute(0, 2, 3, 1, 4).reshape(batch * n_pix, heads, T, 64)
+    o = F.scaled_dot_product_attention(bpthd(q, tq), bpthd(k, tk), bpthd(v, tk))
+    o = o.view(batch, n_pix, heads, tq, 64).permute(0, 3, 1, 2, 4).reshape(batch * tq * n_pix, C)
+    out.copy_(o.to(out.dtype))
+    return out
+
+
+def groupnorm_sums(x, frames, pix, frames_per_stat, groups=32):
+    """[nstat, groups, 2] float64 (sum, sum of squares) over frames_per_stat frames x pix x C/groups."""
+    C = x.shape[1]
+    v = x.double().reshape(frames // frames_per_stat, frames_per_stat * pix, groups, C // groups)
+    return torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1).contiguous()
+
+
+def groupnorm_apply_sums(x, frames, pix, gamma, beta, eps, sums, count, *, frames_per_stat=1, silu=False, groups=32, out=None):
+    C = x.shape[1]
+    mean = sums[..., 0] / count
+    var = (sums[..., 1] / count - mean * mean).clamp_min(0.0)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    v = x.float().reshape(frames // frames_per_stat, frames_per_stat * pix, groups, C // groups)
+    y = (v - mean.float()[:, None, :, None]) * rstd.float()[:, None, :, None]
+    y = y.reshape(frames * pix, C) * gamma + beta
+    if silu:
+        y = F.silu(y)
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False, groups=32, out=None):
+    sums = groupnorm_sums(x, frames, pix, frames_per_stat, groups)
+    count = float(frames_per_stat) * pix * (x.shape[1] // groups)
+    return groupnorm_apply_sums(x, frames, pix, gamma, beta, eps, sums, count, frames_per_stat=frames_per_stat, silu=silu, groups=groups, out=out)
+
+
+def layernorm(x, gamma, beta, *, eps=1e-5, addvec=None, rows_per_vec=0, want_sum=False, silu=False, out=None):
+    v = x.float()
+    if addvec is not None:
+        v = v + addvec[torch.arange(x.shape[0], device=x.device) // rows_per_vec]
+    y = F.layer_norm(v, (x.shape[1],), gamma, beta, eps)
+    if silu:
+        y = F.silu(y)
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        y = out
+    return (y, v.to(x.dtype)) if want_sum else y
+
+
+def nchw_to_tokens(x0, x1, scale, cpad):
+    from streamingt2v_amd import ops
+    F_, c0 = x0.shape[0], x0.shape[1]
+    pix = x0.shape[2] * x0.shape[3]
+    out = torch.zeros((F_, pix, cpad), dtype=torch.float32, device=x0.device)
+    a = x0.float() * (scale[:, None, None, None] if scale is not None else 1.0)
+    out[..., :c0] = a.flatten(2).transpose(1, 2)
+    if x1 is not None:
+        out[..., c0:c0 + x1.shape[1]] = x1.float().flatten(2).transpose(1, 2)
+    return out.reshape(F_ * pix, cpad).to(ops.ELEM)
+
+
+def tokens_to_nchw(x, c, frames, h, w):
+    return x.float()[:, :c].reshape(frames, h * w, c).transpose(1, 2).reshape(frames, c, h, w).contiguous()
+
+
+def concat_channels(a, b):
+    return torch.cat([a, b], 1)
+
+
+def add_rows(x, b):
+    return (x.float() + b.float()).to(x.dtype)
+
+
+def to_elem(x, silu=False):
+    from streamingt2v_amd import ops
+    return (F.silu(x) if silu else x).to(ops.ELEM)
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    from streamingt2v_amd import ops
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], -1).to(ops.ELEM)
+
+
+def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
+    T, C = x.shape[0], x.shape[1]
+    h, w = x.shape[2], x.shape[3]
+    n = net[:, :C].reshape(2, T, h * w, C).permute(0, 1, 3, 2).reshape(2, T, C, h, w)
+    c_skip, c_out = 1.0 / (sigma * sigma + 1.0), -sigma / math.sqrt(sigma * sigma + 1.0)
+    du, dc = n[0] * c_out + x * c_skip, n[1] * c_out + x * c_skip
+    den = du + guidance_scale[:, None, None, None] * (dc - du)
+    x.copy_(x + (x - den) / sigma * (sigma_next - sigma))
+    return x
+
+
+NAMES = ("gemm", "attn_spatial", "attn_temporal", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
+         "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "timestep_embedding", "edm_euler_step")
+
+
+def install(monkeypatch=None):
+    """Route streamingt2v_amd.ops through the statements above, with fp32 'elements' (CPU host-logic tests only)."""
+    import sys
+    from streamingt2v_amd import ops
+    me = sys.modules[__name__]
+    for n in NAMES + ("to_bf16",):
+        fn = getattr(me, "to_elem" if n == "to_bf16" else n)
+        if monkeypatch is not None:
+            monkeypatch.setattr(ops, n, fn, raising=False)
+        else:
+            setattr(ops, n, fn)
+    if monkeypatch is not None:
+        monkeypatch.setattr(ops, "ELEM", torch.float32)
+    else:
+        ops.ELEM = torch.float32

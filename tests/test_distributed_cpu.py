@@ -107,3 +107,95 @@ def test_two_rank_gloo_paths():
         assert ok_blend and ok_blend5 and ok_cfg
         assert tmax == 2.0
         assert items == ([0, 2, 4] if rank == 0 else [1, 3])
+
+
+# ---- sequence parallelism of the denoiser forward (SURVEY.md 8e option 2) + CFG pair + sharded decode, on gloo ranks -------------------
+def _sp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(2)
+    from tests import svd_shim
+    svd_shim.install()                                   # fp32 torch statements of the HIP launchers: the HOST logic is what runs here
+    from oracle import cases
+    from streamingt2v_amd import parallel
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.sampling import EulerEDMSampler
+    from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    assert parallel.init_from_env(backend="gloo") == world
+    try:
+        torch.set_grad_enabled(False)
+        tu = cases.TINY_UNET
+        cfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"], channel_mult=tu["channel_mult"],
+                         conditioning_embedding_out_channels=tu["cond_embed"])
+        unet, cn = VideoUNet(cfg), ControlNet(cfg)
+        unet.load_state_dict(init_by_name(unet.spec(), seed=1), device="cpu")
+        cn.load_state_dict(init_by_name(cn.spec(), seed=2), device="cpu")
+        T, Tc = tu["T"], tu["Tc"]
+        inp = cases.tiny_wrapper_inputs()
+        c = {k: inp[k] for k in ("concat", "crossattn", "vector")}
+        kw = dict(batch_size=2, num_video_frames=T, image_only_indicator=torch.zeros(2, T), ctrl_frames=inp["ctrl_frames"])
+        wrap = StreamingWrapper(unet, cn, Tc)
+        ref = wrap.forward(inp["x"], inp["t"], c, **kw)                       # single process: every rank computes the same reference
+        # (1) sequence parallelism alone over all ranks, CFG batch 2 (B = 2: exercises the batch interleave of the all-to-alls)
+        wrap.sp = parallel.SeqParallel(None)
+        got = wrap.forward(inp["x"], inp["t"], c, **kw)
+        e_sp = (got - ref).abs().max().item()
+        # also without control frames (chunk 0)
+        kw0 = dict(kw, ctrl_frames=None)
+        e_sp0 = (wrap.forward(inp["x"], inp["t"], c, **kw0) - StreamingWrapper(unet, cn, Tc).forward(inp["x"], inp["t"], c, **kw0)).abs().max().item()
+        wrap.sp = None
+        # (2) the job plan of bench.py: CFG pair x SP(world / 2) through the fused sampler, 2 Euler steps
+        sin = cases.tiny_sampler_inputs()
+        z_ref = EulerEDMSampler(num_steps=2, num_frames=T)(wrap, sin["noise"].clone(), sin["c"], sin["uc"], batch_size=2, num_video_frames=T,
+                                                           ctrl_frames=inp["ctrl_frames"])
+        plan = parallel.JobPlan(world, rank, "job")
+
+        class _Vae:
+            decode_group = None
+        vae = _Vae()
+        plan.attach(wrap, vae)
+        z = EulerEDMSampler(num_steps=2, num_frames=T, cfg_exchange=plan.cfg_exchange)(wrap, sin["noise"].clone(), sin["c"], sin["uc"], batch_size=2,
+                                                                                       num_video_frames=T, ctrl_frames=inp["ctrl_frames"])
+        e_job = ((z - z_ref).abs().max() / z_ref.abs().max()).item()
+        # (3) decode groups sharded over the ranks == local decode (stand-in decoder: any function of the group's latents)
+        from streamingt2v_amd.streaming_svd import StreamingSVD
+
+        class _Dec:
+            decode_group = None
+            def decode(self, zc, timesteps=None, clamp=False):
+                return (zc.mean(1, keepdim=True).repeat(1, 3, 1, 1) * timesteps).repeat_interleave(8, 2).repeat_interleave(8, 3).contiguous()
+            @staticmethod
+            def output_shape(zz):
+                return (zz.shape[0], 3, 8 * zz.shape[2], 8 * zz.shape[3])
+        dec = _Dec()
+        zz = torch.randn(11, 4, 2, 3, generator=torch.Generator().manual_seed(3))      # groups of 8 + 3
+        one = StreamingSVD(None, dec).decode_first_stage(zz)
+        dec.decode_group = vae.decode_group
+        two = StreamingSVD(None, dec).decode_first_stage(zz)
+        out.put((rank, e_sp, e_sp0, e_job, torch.equal(one, two), plan.describe(), plan.scaling))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sequence_parallel_forward_equals_single_process(world):
+    """The frame <-> pixel sequence-parallel StreamingWrapper forward (all-to-all around the temporal operators, all-reduced 5-D
+    GroupNorm sums, all-gathered CAM keys / values and network output) reproduces the single-process forward on every rank; so does
+    the CFG-pair x SP job plan through the fused sampler; the sharded decode is bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, e_sp, e_sp0, e_job, dec_ok, desc, scaling in res:
+        assert e_sp < 2e-4 and e_sp0 < 2e-4, (rank, e_sp, e_sp0)          # fp32 on both sides: summation order only
+        assert e_job < 2e-4, (rank, e_job)
+        assert dec_ok and scaling == "strong"
+        assert ("sequence parallelism of degree %d" % (world // 2)) in desc or world == 2
