@@ -70,8 +70,8 @@ struct GemmCfg {
     X(16, 128, 192, 2, 2, 64, true, false, 2) /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */ \
     X(17, 256, 256, 4, 2, 32, true, false, 3) /* 3-stage ring, BK 32: loads 2 K tiles ahead (133 KB)          */ \
     X(18, 256, 128, 4, 2, 64, true, false, 3) /* 3-stage ring (144 KB)                                        */ \
-    X(19, 256, 128, 4, 2, 64, true, false, 12) /* delayed epilogue: stores of tile t inside the K loop of t+1 (kept: measured, never fastest) */ \
-    X(20, 128, 256, 2, 2, 32, true, false, 22) /* ping-pong: 2 groups x (4 waves, 64x128 per wave), BK 32 (kept: measured, never fastest)   */
+    X(19, 256, 128, 4, 2, 32, true, false, 4)  /* 4-stage ring, BK 32: requests 3 K tiles ahead (133 KB)                                  */ \
+    X(20, 256, 256, 2, 4, 64, true, false, 2)  /* 8 with 128x64 wave tiles                                                              */
 #endif
 constexpr int kNumCfg = 20;
 

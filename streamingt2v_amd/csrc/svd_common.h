@@ -104,6 +104,20 @@ __device__ __forceinline__ void svd_wait_vmcnt(int n) {
         default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
     }
 }
+// Coarse form for hot loops: waits for vmcnt(c) with the largest c <= n from a short ladder (waiting for a few more of the OLDEST
+// operations than strictly necessary is always safe) -- at most 4 scalar branches instead of a 64-way switch.
+#define SVD_VMCNT_IMM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+__device__ __forceinline__ void svd_wait_vmcnt_coarse(int n) {
+    if (n >= 8) {
+        if (n >= 24) { if (n >= 48) SVD_VMCNT_IMM(48); else if (n >= 32) SVD_VMCNT_IMM(32); else SVD_VMCNT_IMM(24); }
+        else { if (n >= 16) SVD_VMCNT_IMM(16); else if (n >= 12) SVD_VMCNT_IMM(12); else SVD_VMCNT_IMM(8); }
+    } else if (n >= 4) {
+        if (n >= 6) SVD_VMCNT_IMM(6); else SVD_VMCNT_IMM(4);
+    } else {
+        if (n >= 2) { if (n >= 3) SVD_VMCNT_IMM(3); else SVD_VMCNT_IMM(2); }
+        else { if (n >= 1) SVD_VMCNT_IMM(1); else SVD_VMCNT_IMM(0); }
+    }
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }

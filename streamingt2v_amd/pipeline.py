@@ -231,8 +231,12 @@ class StreamingPipeline:
         return self.model.to_uint8_video(video).cpu().numpy()
 
     # ------------------------------------------------------------------------------------------ enhancement
-    def enhance_video(self, image, video, chunk_size=38, overlap_size=12, strength=0.97, use_randomized_blending=False, **kwargs):
+    def enhance_video(self, image, video, chunk_size=38, overlap_size=12, strength=0.97, use_randomized_blending=False, rng=None, seed=None,
+                      **kwargs):
         """Mirror of enhance_video + i2v_enhance_process (inference_i2v.py:192-207, i2v_enhance_interface.py:82-133).
+        Blending offsets: the reference draws them from Python's GLOBAL `random` stream, seeded once by Lightning's seed_everything
+        (config.yaml:2; pipeline_i2vgen_xl.py:896).  Here the stream is explicit: `rng` (a random.Random, e.g. one shared by several calls
+        to reproduce the reference's single global stream) or `seed` (default: the configured seed, i.e. every call draws the same offsets).
         enhance_codec: enhance_codec.EnhanceCodec (native: AutoencoderKL2D + CLIP towers) or any object with encode_video(frames) ->
         latents [1,4,F,90,160], window_conditioning(images, n_windows, window_len) -> list of dicts(fps, image_latents,
         image_embeddings, text) with the unconditional half first, noise_like(latents), decode(latents) -> uint8 [F,H,W,3]."""
@@ -243,7 +247,10 @@ class StreamingPipeline:
         c, codec = self.cfg, self.enhance_codec
         enh = I2VEnhancer(self.enhancer_unet, getattr(codec, "scheduler", None), guidance_scale=c["enhance_guidance_scale"],
                           num_inference_steps=c["enhance_steps"], strength=strength)
-        rng = random.Random(c["seed"])
+        if kwargs:
+            raise TypeError(f"enhance_video got unexpected keyword arguments {sorted(kwargs)}")
+        if rng is None:
+            rng = random.Random(c["seed"] if seed is None else seed)
         video = list(video)
         images = [resize_key_image(image, getattr(codec, "w", c["enhance_width"]), getattr(codec, "h", c["enhance_height"]))]
         if use_randomized_blending:

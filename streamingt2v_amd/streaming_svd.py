@@ -77,7 +77,11 @@ class StreamingSVD:
     def _generate_initial_chunk(self, c, uc, noise, num_steps=None, min_scale=1.0, max_scale=3.0):
         """Chunk 0 natively: the reference delegates the first 25 frames to diffusers'
         StableVideoDiffusionPipeline (streaming_svd.py:388-390) -- the same UNet without ControlNet/CAM, an Euler step on
-        the Karras/EDM schedule (25 steps) and per-frame guidance 1.0 -> 3.0, decoded in groups of 8 (decode_chunk_size=8)."""
+        the Karras/EDM schedule (25 steps) and per-frame guidance 1.0 -> 3.0, decoded in groups of 8 (decode_chunk_size=8).
+        Known deviations from that third-party call (un-vendored, "parity unpinned"): c / uc come from the sgm-style
+        conditioner of the AR chunks, i.e. the cond frame is augmented with 0.02 * U[0,1) (streaming_svd.py:174) where diffusers adds
+        0.02 * randn and resizes for CLIP with its own antialiasing; and the UNet weights are `model.diffusion_model.*` of the
+        StreamingSVD checkpoint rather than the stock SVD-XT fp16 weights (whether the two are identical is unverified: no checkpoints offline)."""
         from .sampling import EDMDiscretization
         T = self.sampler.guider.num_frames
         num_steps = num_steps or self.initial_num_steps

@@ -104,6 +104,8 @@ def test_ctypes_signatures_match_header_prototypes():
                 want = ctypes.c_int32
             elif p.startswith("float"):
                 want = ctypes.c_float
+            elif p.startswith("double"):
+                want = ctypes.c_double
             else:
                 raise AssertionError(f"{name}: unhandled parameter type in '{p}'")
             if want == "pointer":

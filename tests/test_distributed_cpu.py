@@ -138,8 +138,10 @@ def _sp_worker(rank, world, port, out):
         kw = dict(batch_size=2, num_video_frames=T, image_only_indicator=torch.zeros(2, T), ctrl_frames=inp["ctrl_frames"])
         wrap = StreamingWrapper(unet, cn, Tc)
         ref = wrap.forward(inp["x"], inp["t"], c, **kw)                       # single process: every rank computes the same reference
-        # (1) sequence parallelism alone over all ranks, CFG batch 2 (B = 2: exercises the batch interleave of the all-to-alls)
-        wrap.sp = parallel.SeqParallel(None)
+        # (1) sequence parallelism alone (degree 2: the tiny case has Tc = 3 conditioning frames), CFG batch 2 (B = 2: exercises the batch
+        #     interleave of the all-to-alls); with 4 ranks: two independent SP groups {0,1} and {2,3}
+        sp_groups = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
+        wrap.sp = parallel.SeqParallel(sp_groups[rank // 2])
         got = wrap.forward(inp["x"], inp["t"], c, **kw)
         e_sp = (got - ref).abs().max().item()
         # also without control frames (chunk 0)
