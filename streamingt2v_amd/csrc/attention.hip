@@ -194,6 +194,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
 // happen.  One half-wave (32 lanes) per (batch, pixel, head): lane i holds query i in fp32 registers; K and V of
 // the problem sit in LDS (bf16) and are read as wave-broadcast 16-byte vectors.
 // ------------------------------------------------------------------------------------------------------------
+// Bound: NOT HBM.  Per (pixel, head) the kernel does 2 * T * T * 64 fp32 FMAs on the VALU and re-reads every K / V row from LDS once per
+// query lane: at level 0 of the 576x1024 job that is ~0.2 ms of VALU + ~0.14 ms of LDS time against 0.1 ms of HBM time (590 MB) --
+// measured 0.39 ms.  A round-2 variant with fully cooperative 128-byte global accesses (Q and O staged through LDS) was SLOWER
+// (325 vs 251 us average over the job's launches, profiles/r02_stage1_2steps_kernel_stats.txt history): the next step is MFMA
+// (QK^T and PV as 32x32x16 tiles with V transposed through LDS), not a different load pattern.
 // Three instantiations: <32 keys, 32 lanes, 8 problems per workgroup> (SVD: 25 frames, CAM 25 x 7), <64, 64, 4> (the enhancer's
 // 38-frame windows) and <128, 64, 2> (the enhancer without blending: ONE window of up to 128 frames, the reference's default
 // when --use_randomized_blending is not given).  LANES lanes serve one problem; queries beyond LANES are handled in passes that

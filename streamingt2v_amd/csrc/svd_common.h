@@ -13,7 +13,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 #define SVD_WAVE 64
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division (v_div_scale / v_div_fmas / v_div_fixup: ~10 VALU):
+// every consumer rounds the result to 16 bit or feeds a sampler step; the GroupNorm+SiLU pass is no longer VALU-co-bound.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off class): branch-free, ~14 VALU incl. one rcp
 // and one exp2, against ~35 with branches for ocml's erff -- the GEGLU epilogue evaluates it 16x per fragment per lane.
 __device__ __forceinline__ float erf_as(float x) {

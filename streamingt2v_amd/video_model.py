@@ -194,9 +194,10 @@ def _spec_ff(s, p, c):
 class SpatialVideoTransformer:
     """video_attention.py:174-333 with depth 1, use_linear, ff_in, use_spatial_context (config.yaml:99-113)."""
 
-    def __init__(self, prefix, ch, ctx_dim):
+    def __init__(self, prefix, ch, ctx_dim, use_apm=False, apm_tokens=17):
         assert ch % 64 == 0
         self.p, self.c, self.ctx, self.heads = prefix, ch, ctx_dim, ch // 64
+        self.use_apm, self.apm_tokens = use_apm, apm_tokens
         self._vt = {}
         self._temb = {}
 
@@ -210,6 +211,10 @@ class SpatialVideoTransformer:
         _spec_attn2(s, b + "attn2.", c, ctx)
         for n in ("norm1", "norm2", "norm3"):
             _spec_ln(s, b + n, c)
+        if self.use_apm:        # BasicTransformerBlockWithAPM (attention.py:596-611); registration order: after the parent's modules
+            s.add(b + "apm_alpha")
+            s.add(b + "apm_conv.weight", 1, self.apm_tokens, 3); s.add(b + "apm_conv.bias", 1)
+            _spec_ln(s, b + "apm_ln", ctx)
         s.add(p + "proj_out.weight", c, c); s.add(p + "proj_out.bias", c)
         t = p + "time_stack.0."
         _spec_ln(s, t + "norm_in", c)
@@ -256,6 +261,35 @@ class SpatialVideoTransformer:
         self.tp_w0, self.tp_b0 = W("time_pos_embed.0.weight"), Fv("time_pos_embed.0.bias")
         self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))
+        if self.use_apm:
+            # appearance-preservation front of the spatial block (attention.py:613-619): Conv1d(17 -> 1, k 3, "same") along the 1024-wide
+            # CLIP axis as a [*, 3*17 -> padded 64] GEMM, LayerNorm with the gate silu(alpha) folded into its affine parameters
+            nt = self.apm_tokens
+            wc = g(b + "apm_conv.weight").detach().float()[0]                            # [17, 3]
+            wk = torch.zeros(8, 64)
+            wk[0, : 3 * nt] = wc.t().reshape(-1)                                          # K order (tap, token)
+            self.apm_w = _dev_bf16(wk, dev)
+            self.apm_b = _dev_f32(torch.cat([g(b + "apm_conv.bias").detach().float().reshape(1), torch.zeros(7)]), dev)
+            a = float(g(b + "apm_alpha"))
+            gate = a / (1.0 + math.exp(-a))                                               # F.silu(alpha)
+            self.apm_lnw, self.apm_lnb = _dev_f32(g(b + "apm_ln.weight").detach().float() * gate, dev), _dev_f32(g(b + "apm_ln.bias").detach().float() * gate, dev)
+            # the temporal block cross-attends to all tokens of the first frame's context (video_attention.py:281-285): real attention
+            self.t_ln["norm2"] = (Fv(t + "norm2.weight"), Fv(t + "norm2.bias"))
+            self.t_wq2 = W(t + "attn2.to_q.weight")
+            self.t_wk2 = W(t + "attn2.to_k.weight")
+            self._vt2 = {}
+
+    def _apm_context(self, ctx_tokens):
+        """[F, n_tok, 1024] fp32 -> the spatial block's effective 1-token context [F, 1024]: ctx[:, 0] + LN(conv1d(ctx)) * silu(alpha)."""
+        Fn, nt, L = ctx_tokens.shape
+        assert nt == self.apm_tokens
+        xp = torch.nn.functional.pad(ctx_tokens.float(), (1, 1))                          # "same" padding along the CLIP axis
+        cols = torch.stack([xp[:, :, k:k + L] for k in range(3)], 1)                      # [F, 3, nt, L]: im2col (data movement only)
+        a = torch.zeros((Fn * L, 64), dtype=torch.float32, device=ctx_tokens.device)
+        a[:, : 3 * nt] = cols.reshape(Fn, 3 * nt, L).transpose(1, 2).reshape(Fn * L, 3 * nt)
+        mixed = ops.gemm(ops.to_bf16(a), self.apm_w, bias=self.apm_b, out_f32=True)[:, 0].reshape(Fn, L).contiguous()
+        ln = ops.layernorm(ops.to_bf16(mixed), self.apm_lnw, self.apm_lnb)
+        return ops.add_rows(ln, ops.to_bf16(ctx_tokens[:, 0].float().contiguous()))
 
     def _vt_buf(self, F, pix, x_dtype):
         """V^T staging buffer [F, C, tok_ld]; the pad beyond `pix` stays zero (never written by the GEMM)."""
@@ -286,6 +320,11 @@ class SpatialVideoTransformer:
         (parallel.SeqParallel) x / ctx hold this rank's frames; the temporal block runs in the pixel layout."""
         c, heads, pix = self.c, self.heads, H * W
         M, B = F * pix, tctx.shape[0]
+        tctx_tokens = None
+        if ctx.dim() == 3:                     # APM: [F, 17, 1024] tokens (fp32); tctx [B, 17, 1024]
+            if not self.use_apm:
+                raise NotImplementedError("cross-attention contexts with > 1 token need use_apm (config.yaml:115 ships use_apm: false)")
+            tctx_tokens, ctx = tctx, self._apm_context(ctx)
         h = ops.groupnorm(x, F, pix, self.nw, self.nb, 1e-6, silu=False)
         h = ops.gemm(h, self.wpi, bias=self.bpi)
         # ---- spatial BasicTransformerBlock (attention.py:567-593) ----
@@ -310,8 +349,25 @@ class SpatialVideoTransformer:
         qkv = ops.gemm(n1, self.t_wqkv)
         at = torch.empty((B * T * pt, c), dtype=x.dtype, device=x.device)
         ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pt, heads)
-        v2t = ops.gemm(ops.gemm(tctx, self.t_wv2), self.t_wo2, bias=self.t_bo2, out_f32=True)    # [B, C]
-        xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm)
+        if tctx_tokens is None:
+            v2t = ops.gemm(ops.gemm(tctx, self.t_wv2), self.t_wo2, bias=self.t_bo2, out_f32=True)    # [B, C]
+            xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm)
+        else:
+            # APM: attn2 of the temporal block is a real cross-attention of every (frame, pixel) token to the n_tok context tokens of its
+            # batch element (video_attention.py:150-154 with time_context = context[::T] repeated over pixels)
+            xm = ops.gemm(at, self.t_wo, bias=self.t_bo, residual=xm)
+            nt = tctx_tokens.shape[1]
+            tk = ops.to_bf16(tctx_tokens.float().reshape(B * nt, -1).contiguous())
+            q2 = ops.gemm(ops.layernorm(xm, *self.t_ln["norm2"]), self.t_wq2)
+            k2 = ops.gemm(tk, self.t_wk2)
+            key = (B, x.dtype)
+            vt2 = self._vt2.get(key)
+            if vt2 is None:
+                vt2 = self._vt2[key] = torch.zeros((B, c, 64), dtype=x.dtype, device=x.device)
+            ops.gemm(tk, self.t_wv2, trans_out=dict(tok_per_frame=nt, tokens_ld=64, out=vt2))
+            a2 = torch.empty((B * T * pt, c), dtype=x.dtype, device=x.device)
+            ops.attn_cross(q2, k2, vt2, a2, B, T * pt, nt, 1, heads)
+            xm = ops.gemm(a2, self.t_wo2, bias=self.t_bo2, residual=xm)
         n3 = ops.layernorm(xm, *self.t_ln["norm3"])
         g = ops.gemm(n3, self.t_wf1, bias=self.t_bf1, geglu=True)
         xb = ops.gemm(g, self.t_wf2, bias=self.t_bf2, residual=xm, blend=(self.alpha, ht))     # AlphaBlender
@@ -422,12 +478,13 @@ class UNetConfig:
     def __init__(self, in_channels=8, model_channels=320, out_channels=4, num_res_blocks=2,
                  attention_resolutions=(4, 2, 1), channel_mult=(1, 2, 4, 4), context_dim=1024, adm_in_channels=768,
                  num_head_channels=64, controlnet_mode=True,
-                 conditioning_embedding_out_channels=(32, 96, 256, 512)):
+                 conditioning_embedding_out_channels=(32, 96, 256, 512), use_apm=False, apm_tokens=17):
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions = num_res_blocks, tuple(attention_resolutions)
         self.channel_mult, self.context_dim, self.adm_in_channels = tuple(channel_mult), context_dim, adm_in_channels
         self.num_head_channels, self.controlnet_mode = num_head_channels, controlnet_mode
         self.conditioning_embedding_out_channels = tuple(conditioning_embedding_out_channels)
+        self.use_apm, self.apm_tokens = use_apm, apm_tokens          # config.yaml:115 ships use_apm: false
         assert num_head_channels == 64, "kernels are specialised for head dim 64 (config.yaml:93)"
 
 
@@ -458,7 +515,7 @@ class _EncoderBase:
                 layers = [VideoResBlock(f"input_blocks.{idx}.0.", ch, mult * mc, emb)]
                 ch = mult * mc
                 if ds in cfg.attention_resolutions:
-                    layers.append(SpatialVideoTransformer(f"input_blocks.{idx}.1.", ch, cfg.context_dim))
+                    layers.append(SpatialVideoTransformer(f"input_blocks.{idx}.1.", ch, cfg.context_dim, cfg.use_apm, cfg.apm_tokens))
                 self.input_blocks.append(layers)
                 self.input_block_chans.append(ch)
                 idx += 1
@@ -468,7 +525,7 @@ class _EncoderBase:
                 idx += 1
                 ds *= 2
         self.middle_block = [VideoResBlock("middle_block.0.", ch, ch, emb),
-                             SpatialVideoTransformer("middle_block.1.", ch, cfg.context_dim),
+                             SpatialVideoTransformer("middle_block.1.", ch, cfg.context_dim, cfg.use_apm, cfg.apm_tokens),
                              VideoResBlock("middle_block.2.", ch, ch, emb)]
         self._enc_ch, self._enc_ds = ch, ds
 
@@ -499,13 +556,17 @@ class _EncoderBase:
         B = timesteps.numel() // T
         return sp.take_frames(emb_full, B, T), emb_full, sp.take_frames(ctx, B, T), tctx, B * sp.frame_counts(T)[sp.rank]
 
-    @staticmethod
-    def _contexts(context, T):
-        Fn = context.shape[0]
+    def _contexts(self, context, T):
+        """(per-frame context, per-video context = context[::T]).  One CLIP token per frame (the shipped configuration): 16-bit [F, ctx_dim] /
+        [B, ctx_dim].  Several tokens (APM, use_apm: true): fp32 token tensors [F, n, ctx_dim] / [B, n, ctx_dim]; the spatial blocks reduce
+        them to one effective token (SpatialVideoTransformer._apm_context), the temporal blocks attend to all of them."""
+        if context.dim() == 3 and context.shape[1] != 1:
+            if not self.cfg.use_apm:
+                raise NotImplementedError("cross-attention contexts with >1 token (APM) need UNetConfig(use_apm=True); the shipped "
+                                          "configuration disables it (config.yaml:115 use_apm: false)")
+            context = context.float().contiguous()
+            return context, context[::T].contiguous()
         if context.dim() == 3:
-            if context.shape[1] != 1:
-                raise NotImplementedError("cross-attention contexts with >1 token (APM) are outside the shipped "
-                                          "configuration (config.yaml:115 use_apm: false)")
             context = context[:, 0]
         ctx = ops.to_bf16(context.float().contiguous())
         tctx = ops.to_bf16(context[::T].float().contiguous())       # time_context = context[::T]
@@ -534,7 +595,7 @@ class VideoUNet(_EncoderBase):
                 layers = [VideoResBlock(f"output_blocks.{idx}.0.", ch + ich, mc * mult, emb)]
                 ch = mc * mult
                 if ds in cfg.attention_resolutions:
-                    layers.append(SpatialVideoTransformer(f"output_blocks.{idx}.1.", ch, cfg.context_dim))
+                    layers.append(SpatialVideoTransformer(f"output_blocks.{idx}.1.", ch, cfg.context_dim, cfg.use_apm, cfg.apm_tokens))
                 if level and i == cfg.num_res_blocks:
                     layers.append(_Conv(f"output_blocks.{idx}.{len(layers)}.conv.", ch, ch, ups=1))
                     ds //= 2
