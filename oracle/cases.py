@@ -297,3 +297,11 @@ def fullsize_vae_inputs():
 def fullsize_pixel_subset(n_pixels):
     """seeded random 1/16 of the pixel positions of a frame (sorted), shared by generator and test."""
     return torch.randperm(n_pixels, generator=_gen(7474))[: n_pixels // 16].sort().values
+
+
+# ---- appearance-preservation module (APM): SpatialVideoTransformer(use_apm=True) on a 17-token context (oracle/make_golden_apm.py) ----
+def apm_inputs():
+    g = _gen(1717)
+    C, T, B, H, W = 320, 4, 2, 8, 8
+    return dict(C=C, T=T, seed=17, x=torch.randn(B * T, C, H, W, generator=g),
+                context=torch.randn(B, 1, 17, 1024, generator=g).repeat(1, T, 1, 1).reshape(B * T, 17, 1024) * 0.7)

@@ -102,8 +102,19 @@ def video_res_block(sd, p, x, emb, T):
 
 
 # ---- transformers ---------------------------------------------------------------------------------------------
+def apm_context(sd, p, context):
+    """BasicTransformerBlockWithAPM.forward, attention.py:613-619: a multi-token context [b, 17, 1024] becomes ONE effective token
+    context[:, :1] + LayerNorm(Conv1d(17 -> 1, k 3, "same")(context)) * silu(apm_alpha)."""
+    mixed = F.conv1d(context, sd[p + "apm_conv.weight"], sd[p + "apm_conv.bias"], padding=1)
+    mixed = F.layer_norm(mixed, (context.shape[-1],), sd[p + "apm_ln.weight"], sd[p + "apm_ln.bias"], 1e-5)
+    return context[:, :1] + mixed * F.silu(sd[p + "apm_alpha"])
+
+
 def basic_transformer_block(sd, p, x, context, heads):
-    """BasicTransformerBlock._forward, attention.py:567-593."""
+    """BasicTransformerBlock._forward, attention.py:567-593 (+ the APM front of BasicTransformerBlockWithAPM when its parameters exist and
+    the context carries more than one token)."""
+    if context is not None and context.shape[1] > 1 and (p + "apm_conv.weight") in sd:
+        context = apm_context(sd, p, context)
     x = cross_attention(sd, p + "attn1.", _ln(sd, p + "norm1", x), None, heads) + x
     x = cross_attention(sd, p + "attn2.", _ln(sd, p + "norm2", x), context, heads) + x
     return feed_forward(sd, p + "ff.", _ln(sd, p + "norm3", x)) + x

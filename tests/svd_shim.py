@@ -98,6 +98,17 @@ def attn_temporal(q, k, v, out, batch, tq, tk, n_pix, heads):
     return out
 
 
+def attn_cross(q, k, vt, out, frames, n_q, n_k, frames_per_kv, heads):
+    C = heads * 64
+    nkv = frames // frames_per_kv
+    qh = q.float()[:, :C].reshape(frames, n_q, heads, 64).transpose(1, 2)
+    kh = k.float()[:, :C].reshape(nkv, n_k, heads, 64).transpose(1, 2).repeat_interleave(frames_per_kv, 0)
+    vh = vt.float()[:, :, :n_k].reshape(nkv, heads, 64, n_k).transpose(2, 3).repeat_interleave(frames_per_kv, 0)
+    o = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(frames * n_q, C)
+    out.copy_(o.to(out.dtype))
+    return out
+
+
 def groupnorm_sums(x, frames, pix, frames_per_stat, groups=32):
     """[nstat, groups, 2] float64 (sum, sum of squares) over frames_per_stat frames x pix x C/groups."""
     C = x.shape[1]
@@ -190,7 +201,7 @@ def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
     return x
 
 
-NAMES = ("gemm", "attn_spatial", "attn_temporal", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
+NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
          "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "timestep_embedding", "edm_euler_step")
 
 

@@ -394,3 +394,22 @@ def test_clip_text_tower_vs_oracle(elem):
     with torch.no_grad():                              # clip_skip = 1: the enhancer's prompt path (pipeline_i2vgen_xl.py:246-260, default :645)
         ref1 = text_tower(sd, ids, cfg.heads, clip_skip=1)
     report("CLIP text tower, clip_skip 1", tower(ids, clip_skip=1).reshape(2, 77, 256), ref1)
+
+
+def test_apm_spatial_video_transformer_vs_reference_golden(elem, golden_dir):
+    """Appearance-preservation module (BASELINE north_star names it; config.yaml:115 ships it disabled): SpatialVideoTransformer with
+    use_apm on a 17-token context on the HIP kernels -- Conv1d(17 -> 1) front as a GEMM, LayerNorm with the folded gate, and the temporal
+    block's cross-attention to the 17 tokens through svd_attn_cross_d64 -- vs the UNMODIFIED reference module's output."""
+    from oracle.cases import apm_inputs
+    from streamingt2v_amd.params import Spec, init_by_name
+    from streamingt2v_amd.video_model import SpatialVideoTransformer
+    c = apm_inputs()
+    C, T = c["C"], c["T"]
+    svt = SpatialVideoTransformer("", C, 1024, use_apm=True)
+    spec = Spec(); svt.spec(spec)
+    svt.prepare(init_by_name(spec, seed=c["seed"]), "cuda")
+    Fr, _, H, W = c["x"].shape
+    tok = c["x"].permute(0, 2, 3, 1).reshape(Fr * H * W, C).to(ELEM).cuda().contiguous()
+    ctx = c["context"].cuda()
+    out = svt.forward(tok, ctx, ctx[::T].contiguous(), Fr, T, H, W).float().view(Fr, H, W, C).permute(0, 3, 1, 2)
+    report("SpatialVideoTransformer + APM vs reference", out, torch.load(os.path.join(golden_dir, "apm_svt_tiny.pt"))["out"])

@@ -88,3 +88,36 @@ def test_two_videos_through_one_wrapper_do_not_share_control_state(tiny):
             cn.load_state_dict(tiny["sd_c"], device="cpu")
             fresh = StreamingWrapper(tiny["unet"], cn, tu["Tc"]).forward(inp["x"], inp["t"], c, ctrl_frames=ctrl, **kw)
             assert torch.equal(got, fresh)
+
+
+def test_apm_block_host_logic_vs_reference_golden(monkeypatch, golden_dir):
+    """Appearance-preservation module (use_apm: true; attention.py:596-620): SpatialVideoTransformer on a 17-token context -- the spatial
+    block's Conv1d + LayerNorm + gate front (as a GEMM on an im2col of the CLIP axis) and the temporal block's real cross-attention to the
+    17 tokens -- against the output of the UNMODIFIED reference module (oracle/make_golden_apm.py)."""
+    import os
+    svd_shim.install(monkeypatch)
+    from oracle.cases import apm_inputs
+    from streamingt2v_amd.params import Spec, init_by_name
+    from streamingt2v_amd.video_model import SpatialVideoTransformer
+    c = apm_inputs()
+    C, T = c["C"], c["T"]
+    svt = SpatialVideoTransformer("", C, 1024, use_apm=True)
+    spec = Spec(); svt.spec(spec)
+    svt.prepare(init_by_name(spec, seed=c["seed"]), "cpu")
+    Fr, _, H, W = c["x"].shape
+    tok = c["x"].permute(0, 2, 3, 1).reshape(Fr * H * W, C).contiguous()
+    with torch.no_grad():
+        out = svt.forward(tok, c["context"], c["context"][::T].contiguous(), Fr, T, H, W)
+    out = out.view(Fr, H, W, C).permute(0, 3, 1, 2)
+    gold = torch.load(os.path.join(golden_dir, "apm_svt_tiny.pt"))["out"]
+    assert (out - gold).abs().max().item() < 5e-4, (out - gold).abs().max()
+    # a one-token context through a use_apm block takes the plain path (attention.py:614: context.shape[1] > 1)
+    plain = SpatialVideoTransformer("", C, 1024, use_apm=False)
+    spec2 = Spec(); plain.spec(spec2)
+    sd = init_by_name(spec, seed=c["seed"])
+    plain.prepare(sd, "cpu")
+    one = c["context"][:, :1].contiguous()
+    from streamingt2v_amd import ops
+    ctx1, tctx1 = ops.to_bf16(one[:, 0].contiguous()), ops.to_bf16(one[::T, 0].contiguous())
+    with torch.no_grad():
+        assert torch.equal(svt.forward(tok, ctx1, tctx1, Fr, T, H, W), plain.forward(tok, ctx1, tctx1, Fr, T, H, W))
