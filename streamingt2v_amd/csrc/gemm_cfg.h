@@ -36,7 +36,7 @@ struct GemmCfg {
     static constexpr bool DELAYED_EPI = DELAY_ && !TRANS_ && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64);
     static constexpr bool EPI_DEDICATED = DELAYED_EPI || (WM * WN * EPI_WAVE_BYTES > STAGE_BYTES);   // else: reuse the consumed stage buffer
     // aux slots: bias slice + per-frame vectors of up to AUX_NRV frames, DMA'd at tile setup (2 slots: current / prefetched tile)
-    static constexpr int AUX_NRV = 4;
+    static constexpr int AUX_NRV = (2 * (BM_ + BN_) * BK_ * 2 >= 144 * 1024) ? 2 : 4;   // fewer per-frame vector rows when the stage ring leaves < 16 KB
     static constexpr int AUX_INSTR = (BN + 255) / 256;
     static constexpr int AUX_SLOT_BYTES = (1 + AUX_NRV) * AUX_INSTR * 1024;
     static constexpr int AUX_OFF = LDS_BYTES + (EPI_DEDICATED ? WM * WN * EPI_WAVE_BYTES : 0);
@@ -71,9 +71,11 @@ struct GemmCfg {
     X(17, 256, 256, 4, 2, 32, true, false, 3) /* 3-stage ring, BK 32: loads 2 K tiles ahead (133 KB)          */ \
     X(18, 256, 128, 4, 2, 64, true, false, 3) /* 3-stage ring (144 KB)                                        */ \
     X(19, 256, 128, 4, 2, 32, true, false, 4)  /* 4-stage ring, BK 32: requests 3 K tiles ahead (133 KB)                                  */ \
-    X(20, 256, 256, 2, 4, 64, true, false, 2)  /* 8 with 128x64 wave tiles                                                              */
+    X(20, 256, 256, 2, 4, 64, true, false, 2)  /* 8 with 128x64 wave tiles                                                              */ \
+    X(21, 256, 320, 4, 2, 64, true, false, 2)  /* N = 320 k exactly (320 / 640 / 960 / 1280 ...), 8 waves, 64x160 per wave (157 KB)     */ \
+    X(22, 128, 320, 4, 2, 64, true, false, 2)  /* same, 32x160 per wave                                                                 */
 #endif
-constexpr int kNumCfg = 20;
+constexpr int kNumCfg = 22;
 
 #define X(id, bm, bn, wm, wn, bk, glds, tr, ns) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr, (ns) % 10, (((ns) / 10) & 1) != 0, (((ns) / 10) & 2) != 0>;   /* tens digit: 1 = delayed epilogue, 2 = ping-pong */
 SVD_GEMM_CONFIGS(X)

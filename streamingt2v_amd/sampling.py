@@ -3,16 +3,15 @@
 Mirrors:
   AlignYourSteps                      <- code/models/diffusion/discretizer.py:8-33 (+ append_zero, sgm discretizer.py:18-22)
   VScalingWithEDMcNoise               <- code/models/svd/sgm/modules/diffusionmodules/denoiser_scaling.py:51-59
-  Denoiser                            <- .../denoiser.py:11-39
+  Denoiser (fused: svd_edm_euler_step) <- .../denoiser.py:11-39
   LinearPredictionGuider              <- .../guiders.py:60-99
   EulerEDMSampler (s_churn = 0)       <- .../sampling.py:41-52, 93-130, 211-215
 
 The sigma schedule is float64 on the host exactly as in the reference; per-step sigmas reach the kernels as fp32.
-Two ways to run a step:
-  * reference-shaped: ``Denoiser``/``LinearPredictionGuider`` objects + any ``network(x, c_noise, cond, **kw)``
-    callable (used by the drop-in tests);
-  * fused (``EulerEDMSampler.__call__`` with a StreamingWrapper): the c_in scaling rides in the NCHW->token
-    conversion kernel and denoiser-combine + guidance + Euler update are one kernel on the fp32 state.
+One fused way to run a step (``EulerEDMSampler.__call__`` with a StreamingWrapper): the c_in scaling rides in the NCHW->token conversion
+kernel, and denoiser-combine + guidance + Euler update are one kernel on the fp32 state.  The reference-shaped route -- the reference's OWN
+``EulerEDMSampler`` / ``Denoiser`` objects calling ``StreamingWrapper.forward(x * c_in, c_noise, cond, **kw)`` -- needs nothing from this
+module: the wrapper keeps the reference's forward contract.
 """
 import math
 

@@ -413,3 +413,37 @@ def test_apm_spatial_video_transformer_vs_reference_golden(elem, golden_dir):
     ctx = c["context"].cuda()
     out = svt.forward(tok, ctx, ctx[::T].contiguous(), Fr, T, H, W).float().view(Fr, H, W, C).permute(0, 3, 1, 2)
     report("SpatialVideoTransformer + APM vs reference", out, torch.load(os.path.join(golden_dir, "apm_svt_tiny.pt"))["out"])
+
+
+def test_groupnorm_sums_and_sequence_parallel_path_on_one_rank(tiny):
+    """The sequence-parallel code path on the REAL kernels: svd_groupnorm_sums / svd_groupnorm_stats_from_sums vs torch, and the SP
+    forward over a one-rank RCCL group (layout changes degenerate, every SP branch of the networks runs: pooled GroupNorms from summed
+    statistics, pixel-layout temporal operators, gathered CAM keys / values and network output) == the plain forward."""
+    import socket
+    import torch.distributed as dist
+    from streamingt2v_amd import ops, parallel
+    g = torch.Generator(); g.manual_seed(3)
+    Fr, pix, C, fps = 6, 40, 320, 3
+    x = (torch.randn(Fr * pix, C, generator=g) * 1.5 + 0.5).to(ELEM).cuda()
+    sums = ops.groupnorm_sums(x, Fr, pix, fps)
+    v = x.double().view(Fr // fps, fps * pix, 32, C // 32)
+    ref = torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)
+    assert torch.allclose(sums, ref, rtol=1e-5, atol=1e-3), (sums - ref).abs().max()
+    gam, bet = torch.randn(C, generator=g).cuda() * 0.1 + 1, torch.randn(C, generator=g).cuda() * 0.1
+    a = ops.groupnorm_apply_sums(x, Fr, pix, gam, bet, 1e-5, sums, float(fps * pix * (C // 32)), frames_per_stat=fps, silu=True)
+    b = ops.groupnorm(x, Fr, pix, gam, bet, 1e-5, frames_per_stat=fps, silu=True)
+    assert (a.float() - b.float()).abs().max().item() <= 2e-2 * (1.0 if ELEM == torch.bfloat16 else 0.125)
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    tu, wrap = tiny["tu"], tiny["wrap"]
+    inp = _cuda(tiny["cases"].tiny_wrapper_inputs())
+    c = {k: inp[k] for k in ("concat", "crossattn", "vector")}
+    kw = dict(batch_size=2, num_video_frames=tu["T"], image_only_indicator=torch.zeros(2, tu["T"], device="cuda"), ctrl_frames=inp["ctrl_frames"])
+    ref = wrap.forward(inp["x"], inp["t"], c, **kw)
+    try:
+        wrap.sp = parallel.SeqParallel(None)
+        got = wrap.forward(inp["x"], inp["t"], c, **kw)
+    finally:
+        wrap.sp = None
+    report("sequence-parallel path (1 rank) vs plain forward", got, ref, rel_tol=1e-2)
