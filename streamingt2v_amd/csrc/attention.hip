@@ -131,10 +131,27 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
         m_run = m_new;
         // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): the softmax is VALU-bound (32 exp2 + ~110 other VALU ops per tile
         // against 16 MFMAs), so two scores per instruction where the ISA has it
+        uint32_t pk[2][8];
+#ifdef SVD_ATTN_SCALAR_SOFTMAX   /* A/B build (profiles/r02_attn_packed_vs_scalar.txt: +1 % = noise): single-issue fp32 ops instead of the packed forms */
+        const float mneg = -m_new;
+        float psa = 0.f, psb = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float e0, e1;
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(s_acc[kb][r]), "v"(c), "v"(mneg));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(s_acc[kb][r + 1]), "v"(c), "v"(mneg));
+                const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(psa) : "v"(psa), "v"(p0));
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(psb) : "v"(psb), "v"(p1));
+                pk[kb][r >> 1] = E::pack(p0, p1);
+            }
+        l_run = l_run * alpha + (psa + psb);
+#else
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 c2 = {c, c}, m2 = {-m_new, -m_new};
         f32x2 ps2 = {0.f, 0.f};
-        uint32_t pk[2][8];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -148,6 +165,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
                 pk[kb][r >> 1] = E::pack(pv[0], pv[1]);
             }
         l_run = l_run * alpha + (ps2[0] + ps2[1]);
+#endif
         if (rescale) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o_acc[0][i] *= alpha; o_acc[1][i] *= alpha; }

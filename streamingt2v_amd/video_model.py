@@ -364,7 +364,9 @@ class SpatialVideoTransformer:
             vt2 = self._vt2.get(key)
             if vt2 is None:
                 vt2 = self._vt2[key] = torch.zeros((B, c, 64), dtype=x.dtype, device=x.device)
-            ops.gemm(tk, self.t_wv2, trans_out=dict(tok_per_frame=nt, tokens_ld=64, out=vt2))
+            # V^T [B, C, 64]: 17 tokens per batch element are not a multiple of the 4-token store width of the GEMM's transposed-output
+            # mode, so the (tiny: B x 17 x C) transpose is a copy here
+            vt2[:, :, :nt] = ops.gemm(tk, self.t_wv2).view(B, nt, c).transpose(1, 2)
             a2 = torch.empty((B * T * pt, c), dtype=x.dtype, device=x.device)
             ops.attn_cross(q2, k2, vt2, a2, B, T * pt, nt, 1, heads)
             xm = ops.gemm(a2, self.t_wo2, bias=self.t_bo2, residual=xm)

@@ -1,0 +1,47 @@
+"""CPU suite: the bookkeeping of bench.py's default workload -- the chunk sequence of consecutive 100-frame stage-1 jobs and the frames each
+chunk contributes to `value` -- against the reference's own chunk arithmetic (inference_i2v.py:179-190, streaming_svd.py:293-356)."""
+import math
+
+import torch
+
+
+class _FakeModel:
+    num_conditional_frames = 7
+
+    def __init__(self):
+        self.calls = []
+
+    @staticmethod
+    def quantize_like_pil(x):
+        return x
+
+    @staticmethod
+    def extract_ctrl_frames(video, n):
+        return video[-n:][None]
+
+    def _generate_initial_chunk(self, c, uc, noise):
+        self.calls.append(("chunk0", None))
+        return torch.zeros(25, 3, 2, 2)
+
+    def _generate_conditional_output(self, c, uc, ctrl, noise):
+        self.calls.append(("ar", float(ctrl.mean())))
+        return torch.full((25, 3, 2, 2), float(len(self.calls)))
+
+    @staticmethod
+    def to_uint8_video(v):
+        return v
+
+
+def test_stage1_stream_walks_the_reference_sequence():
+    import bench
+    m = _FakeModel()
+    s = bench.Stage1Stream(m, None, None, [None] * 6)
+    kept = [s.step() for _ in range(13)]
+    assert kept == [25, 18, 18, 18, 18, 3, 25, 18, 18, 18, 18, 3, 25]
+    # the reference: ceil((100 - 25) / (25 - 7)) = 5 AR chunks, 25 + 5 * 18 = 115 frames cut to 100
+    n_ar = math.ceil((100 - 25) / (25 - 7))
+    assert n_ar == 5 and sum(bench.Stage1Stream.KEPT) == 100 and 25 + n_ar * 18 == 115
+    assert [c[0] for c in m.calls[:7]] == ["chunk0", "ar", "ar", "ar", "ar", "ar", "chunk0"]
+    # every AR chunk is driven by the frames the PREVIOUS chunk produced (chunk 0 -> zeros; AR k -> the constant of call k)
+    assert m.calls[1][1] == 0.0 and m.calls[2][1] == 2.0 and m.calls[3][1] == 3.0
+    assert s.video_u8.shape[0] == 100

@@ -1,3 +1,4 @@
+# K-loop timing probes (GPU box): builds are made with `make -C streamingt2v_amd/csrc pvariant NAME=<v> PROBE_DEFS=...` (see Makefile), one .so per variant; this script times them.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for v in base nobar static stnb nods all3; do
