@@ -18,6 +18,7 @@ bool cfg_ok(const svd_gemm_args& a) {
     if (kq % CFG::BK != 0 || a.K % CFG::BK != 0) return false;
     if (CFG::TRANS != (a.out_mode == SVD_OUT_BF16_T)) return false;
     if ((a.epi_flags & SVD_EPI_GEGLU) && (CFG::FN % 2 != 0)) return false;   // value|gate frag pairs per wave
+    if (a.a_mode == SVD_A_CONV3X3 && a.ups && !CFG::UPS_KERNEL) return false; // the folded-upsample kernel exists for a subset of the tiles
     return true;
 }
 
@@ -80,7 +81,7 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
     if (a.K % 32 != 0) return SVD_EINVAL;
     {   // the kernel's A-operand offsets are 32-bit ELEMENT offsets (gemm_impl.inc a_off / pix * lda): reject sources they cannot reach
         int64_t src_rows = a.M;
-        if (a.a_mode == SVD_A_CONV3X3) src_rows = (int64_t)(a.M / (a.hout * a.wout)) * a.hin * a.win;
+        if (a.a_mode == SVD_A_CONV3X3) src_rows = (int64_t)(a.M / (a.hout * a.wout)) * a.hin * a.win + a.win + 2;   // + one row and column: offsets are taken from tap (1, 1)
         if (src_rows * a.lda >= ((int64_t)1 << 32)) return SVD_EINVAL;
     }
     if (a.rowvec && a.rows_per_vec <= 0) return SVD_EINVAL;
@@ -92,7 +93,8 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
     if (a.epi_flags & SVD_EPI_GEGLU) {
         if (a.N % 64 != 0 || a.out_mode != SVD_OUT_BF16) return SVD_EINVAL;
     }
-    const int cfg = a.tile_cfg > 0 ? a.tile_cfg : pick_cfg(a);
+    int cfg = a.tile_cfg > 0 ? a.tile_cfg : pick_cfg(a);
+    if (a.tile_cfg > 0 && a.a_mode == SVD_A_CONV3X3 && a.ups && svd_gemm_config_valid(args, cfg) != 1) cfg = pick_cfg(a);   // a tuned table from before the subset
     if (svd_gemm_config_valid(args, cfg) != 1) return SVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (a.dtype == SVD_DTYPE_BF16) return svd_gemm_launch_bf16(a, cfg, s);

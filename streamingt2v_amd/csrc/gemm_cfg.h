@@ -9,6 +9,12 @@
 namespace svd_gemm_detail {
 
 
+// internal A-operand view: 3x3 convolution whose source is read through a folded nearest-2x upsample (svd_gemm_args.ups = 1)
+#define SVD_A_CONV3X3_UPS 3
+
+#ifndef SVD_GEMM_FRAG_SETS_MAX
+#define SVD_GEMM_FRAG_SETS_MAX 2      /* 1: A/B switch, single fragment set, scheduler's own order */
+#endif
 template <int BM_, int BN_, int WM_, int WN_, int BK_, bool GLDS_, bool TRANS_, int NS_ = 2, bool DELAY_ = false, bool PP_ = false>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
@@ -20,6 +26,14 @@ struct GemmCfg {
     // register budget: 4-wave workgroups with <= 64 accumulator registers per lane must fit twice per SIMD (2 WG / CU)
     static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && WM * WN == 4 && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64 || BK_ == 32)) ? ((BK_ == 32 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? SVD_GEMM_BK32_WAVES : 2) : 1;   // BK 32 + 128 accumulators: 2 x 58 KB LDS, 256 registers
     static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+    // tiles that also carry the folded-upsample convolution kernel (the Upsample layers of the UNet and of the VAE decoder): the heuristic's
+    // picks and the shapes the tuner has chosen for those layers -- not all 22, to bound build time
+    static constexpr bool UPS_KERNEL = !TRANS_ && !PP_ && ((BM_ == 128 && (BN_ == 128 || BN_ == 64 || BN_ == 320) && WM_ == 2 && NS_ == 2) || (BM_ == 256 && (BN_ == 128 || BN_ == 256 || BN_ == 320) && WM_ * WN_ == 8 && BK_ == 64));
+    // fragment register sets of the k-step software pipeline (gemm_impl.inc compute()): two when accumulators + 2 x fragments leave
+    // ~70 registers for addresses / epilogue state inside the wave's share of the 512-entry register file.
+    static constexpr int WAVES_PER_SIMD = (THREADS / 256 > MIN_WAVES_PER_SIMD) ? THREADS / 256 : MIN_WAVES_PER_SIMD;
+    static constexpr int REG_BUDGET = 512 / WAVES_PER_SIMD;
+    static constexpr int FRAG_SETS = (SVD_GEMM_FRAG_SETS_MAX >= 2 && FM * FN * 16 + 2 * (FM + FN) * 4 + 70 <= REG_BUDGET) ? 2 : 1;
     static constexpr int ROWB = BK * 2;       // bytes per LDS row
     static constexpr int SLOTS = BK / 8;      // 16-byte slots per row
     static constexpr int SW_SHIFT = (BK == 64) ? 1 : 2;

@@ -16,20 +16,22 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division (v_div_scale / v_div_fmas / v_div_fixup: ~10 VALU):
 // every consumer rounds the result to 16 bit or feeds a sampler step; the GroupNorm+SiLU pass is no longer VALU-co-bound.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off class): branch-free, ~14 VALU incl. one rcp
-// and one exp2, against ~35 with branches for ocml's erff -- the GEGLU epilogue evaluates it 16x per fragment per lane.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * ax * ax);
-    return copysignf(fmaf(-p * t, e, 1.0f), x);
+// exact-erf GELU of the reference's GEGLU (attention.py:99-101):  gelu(x) = x Phi(x) = max(x, 0) - |x| q(|x|),  q(t) = Phi(-t) = 2^(r(t) - 1),
+// r(t) = log2 erfc(t / sqrt 2) by a degree-6 polynomial without constant term (weighted minimax fit on [0, 7], |erf error| <= 2.3e-7; q(7) is
+// 6e-13, so t is clamped there).  ONE transcendental (v_exp_f32) per element against two (rcp + exp2) for the Abramowitz-Stegun 7.1.26 form used before, no sign
+// transfer, and the relative accuracy of the negative tail comes for free: |gelu error| <= 2e-6 absolute over the whole fp32 range (numpy
+// float32 emulation of this exact sequence), i.e. 1/100 of the 16-bit output rounding.  The GEGLU epilogue of the ff1 GEMMs is bound by
+// exactly this arithmetic (VALU is per SIMD: both waves' 64 gate values per lane serialise; round-2 ISA audit).
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float t = fminf(fabsf(x), 7.0f);
+    float r = fmaf(1.775515804e-05f, t, -6.477575890e-04f);
+    r = fmaf(r, t, 7.724042874e-03f);
+    r = fmaf(r, t, -5.292673725e-02f);
+    r = fmaf(r, t, -4.590827371e-01f);
+    r = fmaf(r, t, -1.151116856e+00f);
+    const float q = __builtin_amdgcn_exp2f(fmaf(r, t, -1.0f));
+    return fmaf(-fabsf(x), q, fmaxf(x, 0.0f));
 }
-// exact-erf GELU of the reference's GEGLU (attention.py:99-101)
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -85,10 +87,15 @@ struct ElemF16 {
 // count it: with the builtin form the compiler drains vmcnt(0) before the next ds_read of ANY LDS address, which
 // serialises staging and MFMA.  The caller owns the wait: asm s_waitcnt vmcnt(0) (svd_wait_dma) + barrier before
 // the staged tile is read.  `lds_dst` must be wave-uniform (byte address of the wave's 1 KiB destination).
+// M0 (the LDS base of the DMA) is written and NOT restored: nothing else in these kernels reads M0 (gfx9+ LDS instructions do not need
+// it; SGPR spills use immediate lanes) -- tools/check_isa.py asserts that on the built objects.  The save/restore pair cost two scalar
+// issue slots per DMA instruction in the GEMM K loop.
 __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+// SADDR form: wave-uniform 64-bit base (SGPR pair) + unsigned 32-bit per-lane byte offset -- no 64-bit vector add per instruction.
+__device__ __forceinline__ void glds16_saddr(uint32_t voff, const void* sbase, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void svd_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate; n > 63 waits for 63: safe, just earlier)
