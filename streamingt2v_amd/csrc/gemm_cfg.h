@@ -87,9 +87,10 @@ struct GemmCfg {
     X(19, 256, 128, 4, 2, 32, true, false, 4)  /* 4-stage ring, BK 32: requests 3 K tiles ahead (133 KB)                                  */ \
     X(20, 256, 256, 2, 4, 64, true, false, 2)  /* 8 with 128x64 wave tiles                                                              */ \
     X(21, 256, 320, 4, 2, 64, true, false, 2)  /* N = 320 k exactly (320 / 640 / 960 / 1280 ...), 8 waves, 64x160 per wave (157 KB)     */ \
-    X(22, 128, 320, 4, 2, 64, true, false, 2)  /* same, 32x160 per wave                                                                 */
+    X(22, 128, 320, 4, 2, 64, true, false, 2)  /* same, 32x160 per wave                                                                 */ \
+    X(23, 128, 256, 2, 2, 32, true, false, 2)  /* 4 waves, 64x128 per wave, BK 32: 58 KB -> TWO workgroups per CU (one's epilogue under the other's MFMAs) */
 #endif
-constexpr int kNumCfg = 22;
+constexpr int kNumCfg = 23;
 
 #define X(id, bm, bn, wm, wn, bk, glds, tr, ns) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr, (ns) % 10, (((ns) / 10) & 1) != 0, (((ns) / 10) & 2) != 0>;   /* tens digit: 1 = delayed epilogue, 2 = ping-pong */
 SVD_GEMM_CONFIGS(X)

@@ -168,7 +168,8 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
 def attn_spatial(q, k, vt, out, frames, n_tok, heads):
     """q,k: views into a [frames*n_tok, ld] tensor at the head-0 column; vt: [frames, heads*64, tok_ld]."""
     if trace is not None:
-        with trace.launch("attn_spatial_d64", flops=4.0 * frames * heads * n_tok * n_tok * 64):
+        with trace.launch("attn_spatial_d64", flops=4.0 * frames * heads * n_tok * n_tok * 64, sig=f"attn_spatial_f{frames}_n{n_tok}_h{heads}",
+                          nbytes=4.0 * frames * n_tok * heads * 64 * 2):
             check(_lib.svd_attn_spatial_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out),
                                             out.stride(0), frames, n_tok, heads, _dt(q), _stream()), "svd_attn_spatial_d64")
         return out

@@ -45,3 +45,21 @@ def test_stage1_stream_walks_the_reference_sequence():
     # every AR chunk is driven by the frames the PREVIOUS chunk produced (chunk 0 -> zeros; AR k -> the constant of call k)
     assert m.calls[1][1] == 0.0 and m.calls[2][1] == 2.0 and m.calls[3][1] == 3.0
     assert s.video_u8.shape[0] == 100
+
+
+def test_roofline_groups_the_gemm_instantiations_into_one_kernel_family():
+    import bench
+
+    class _Trace:
+        def summarize(self):      # {name: [launches, flops, ms, {signature: [launches, flops, ms, algorithmic bytes]}]}
+            return {"gemm_cfg20_mode0": [10, 10e12, 10.0, {"m0_A": [10, 10e12, 10.0, 1e9]}],
+                    "gemm_cfg21_mode1": [5, 8e12, 8.0, {"m1_B": [5, 8e12, 8.0, 2e9]}],
+                    "attn_spatial_d64": [4, 12e12, 12.0, {"attn_spatial_f50_n9216_h5": [4, 12e12, 12.0, 3e8]}],
+                    "gn_apply": [20, 0.0, 3.0, {"gn_apply": [20, 0.0, 3.0, 0.0]}]}
+
+    r = bench.roofline_from_trace(_Trace())
+    assert r["kernel"].startswith("gemm_kernel") and r["instantiations"] == 2 and r["launches"] == 15
+    assert abs(r["achieved"] - 1000.0) < 1e-6 and abs(r["frac"] - 0.4) < 1e-6          # 18e12 flop / 18 ms
+    assert abs(r["share_of_traced_time"] - 18.0 / 33.0) < 1e-3
+    assert r["traffic"]["signature"] == "m0_A" and r["traffic"]["algorithmic_bytes_per_launch"] == 1e9
+    assert set(r["traced_kernels"]) == {"gemm_cfg20_mode0", "gemm_cfg21_mode1", "attn_spatial_d64", "gn_apply"}
