@@ -213,7 +213,8 @@ def test_attn_spatial_online_softmax_rescale(ops):
     check("attn spatial spiked key", out, ref, 2e-2, 2e-2)
 
 
-@pytest.mark.parametrize("B,Tq,Tk,pix,heads", [(2, 25, 25, 33, 5), (2, 25, 7, 20, 10), (1, 7, 7, 9, 20), (2, 8, 3, 16, 5)])
+@pytest.mark.parametrize("B,Tq,Tk,pix,heads", [(2, 25, 25, 33, 5), (2, 25, 7, 20, 10), (1, 7, 7, 9, 20), (2, 8, 3, 16, 5),
+                                                 (1, 32, 32, 7, 2), (2, 25, 17, 9, 5), (1, 25, 32, 4, 3), (3, 1, 1, 5, 1), (2, 25, 25, 2304, 10)])
 def test_attn_temporal(ops, B, Tq, Tk, pix, heads):
     C = heads * 64
     q = rnd(B * Tq * pix, C, seed=27)
