@@ -128,15 +128,21 @@ class VideoResBlock:
         self.tw2, self.tb2 = _dev_bf16(pack_tconv3(g(t + "out_layers.3.weight")), dev), _dev_f32(g(t + "out_layers.3.bias"), dev)
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))   # image_only_indicator == 0 (util.py:341-357)
 
-    def forward(self, x, emb_silu, F, T, H, W, sp=None, emb_full=None):
+    def forward(self, x, emb_silu, F, T, H, W, sp=None, emb_full=None, emb_out=None):
         """x [F*H*W, C]: the frames this rank holds (all B*T of them without sequence parallelism; then emb_silu is also the
         embedding of all frames).  With `sp` (parallel.SeqParallel): emb_silu = embedding rows of the LOCAL frames (2-D part),
-        emb_full = rows of all B*T frames (the time_stack runs in the pixel layout, where every rank sees all frames)."""
+        emb_full = rows of all B*T frames (the time_stack runs in the pixel layout, where every rank sees all frames).
+        emb_out = (rows of the local frames, rows of all frames) of the network's PACKED emb_layers output (_EncoderBase._pack_emb_layers):
+        this block's two Linear(emb -> cout) results are column slices of it (without it the block applies its own two Linear layers)."""
         pix = H * W
+        e_pre = et_pre = None
+        if emb_out is not None:
+            e_pre = emb_out[0][:, self.e_off:self.e_off + self.cout]
+            et_pre = (emb_out[0] if sp is None else emb_out[1])[:, self.et_off:self.et_off + self.cout]
         cv_in = dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F)
         cv = dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F)
         h = ops.groupnorm(x, F, pix, self.n1w, self.n1b, 1e-5, silu=True)
-        e = ops.gemm(emb_silu, self.we, bias=self.be, out_f32=True)
+        e = e_pre if e_pre is not None else ops.gemm(emb_silu, self.we, bias=self.be, out_f32=True)
         h = ops.gemm(h, self.w1, bias=self.b1, rowvec=e, rows_per_vec=pix, conv=cv_in)
         h = ops.groupnorm(h, F, pix, self.n2w, self.n2b, 1e-5, silu=True)
         skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
@@ -145,20 +151,20 @@ class VideoResBlock:
             # time_stack: 5-D GroupNorm statistics pool over the T frames of a batch element (video_model.py:75-80)
             tv = dict(cin=self.cout, T=T, pix=pix)
             g = ops.groupnorm(hs, F, pix, self.tn1w, self.tn1b, 1e-5, frames_per_stat=T, silu=True)
-            et = ops.gemm(emb_silu, self.twe, bias=self.tbe, out_f32=True)
+            et = et_pre if et_pre is not None else ops.gemm(emb_silu, self.twe, bias=self.tbe, out_f32=True)
             g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pix, temporal=tv)
             g = ops.groupnorm(g, F, pix, self.tn2w, self.tn2b, 1e-5, frames_per_stat=T, silu=True)
             # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip)
             return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(self.alpha, hs), temporal=tv)
         # sequence parallel: the whole time_stack in the PIXEL layout (all T frames of this rank's pixel range); its two norms pool
         # over every frame and pixel -> all-reduce of the sums
-        B = emb_full.shape[0] // T
+        B = (emb_out[1] if emb_out is not None else emb_full).shape[0] // T
         pl = sp.pix_local(pix)
         hp = sp.to_pixels(hs, B, T, pix)
         tv = dict(cin=self.cout, T=T, pix=pl)
         cnt = float(T) * pix * (self.cout // 32)
         g = _gn_pooled(hp, B * T, pl, self.tn1w, self.tn1b, 1e-5, T, cnt, sp, True)
-        et = ops.gemm(emb_full, self.twe, bias=self.tbe, out_f32=True)
+        et = et_pre if et_pre is not None else ops.gemm(emb_full, self.twe, bias=self.tbe, out_f32=True)
         g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pl, temporal=tv)
         g = _gn_pooled(g, B * T, pl, self.tn2w, self.tn2b, 1e-5, T, cnt, sp, True)
         out = ops.gemm(g, self.tw2, bias=self.tb2, residual=hp, blend=(self.alpha, hp), temporal=tv)
@@ -200,6 +206,7 @@ class SpatialVideoTransformer:
         self.use_apm, self.apm_tokens = use_apm, apm_tokens
         self._vt = {}
         self._temb = {}
+        self._a2c = None          # per-chunk constants of the one-token cross-attentions (_attn2_const)
 
     def spec(self, s):
         p, c, ctx = self.p, self.c, self.ctx
@@ -230,6 +237,7 @@ class SpatialVideoTransformer:
         s.add(p + "time_mixer.mix_factor", 1)
 
     def prepare(self, sd, dev):
+        self._a2c = None
         p = self.p
         g = lambda k: sd[p + k]
         W = lambda k: _dev_bf16(g(k), dev)
@@ -315,6 +323,19 @@ class SpatialVideoTransformer:
             self._temb[key] = e
         return e
 
+    def _attn2_const(self, ctx, tctx):
+        """With ONE context token the cross-attention (attn2) of both transformer blocks is softmax over a single key == 1: its output is
+        to_out(to_v(context)), one vector per frame (spatial) / per video (temporal), independent of the hidden state (K3 shortcut).  The
+        context is the same tensor for every Euler step of a chunk (sampling.py builds the CFG-concatenated conditioning once per chunk and
+        _EncoderBase._local_conditioning maps one input tensor to one ctx object), so the four tiny GEMMs run once per chunk, not once per
+        step: keyed on the IDENTITY of the ctx / tctx objects (held here, so an address can never be reused for different values)."""
+        c = self._a2c
+        if c is None or c[0] is not ctx or c[1] is not tctx or c[2] != ops.ELEM:
+            v2 = ops.gemm(ops.gemm(ctx, self.s_wv2), self.s_wo2, bias=self.s_bo2, out_f32=True)
+            v2t = None if tctx is None else ops.gemm(ops.gemm(tctx, self.t_wv2), self.t_wo2, bias=self.t_bo2, out_f32=True)
+            self._a2c = c = (ctx, tctx, ops.ELEM, v2, v2t)
+        return c[3], c[4]
+
     def forward(self, x, ctx, tctx, F, T, H, W, sp=None):
         """x [F*H*W, C]; ctx [F, ctx_dim] bf16 (per-frame CLIP token); tctx [B, ctx_dim] (= context[::T]).  With `sp`
         (parallel.SeqParallel) x / ctx hold this rank's frames; the temporal block runs in the pixel layout."""
@@ -334,7 +355,7 @@ class SpatialVideoTransformer:
         ops.gemm(n1, self.s_wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
         a = torch.empty((M, c), dtype=x.dtype, device=x.device)
         ops.attn_spatial(qk[:, :c], qk[:, c:], vt, a, F, pix, heads)
-        v2 = ops.gemm(ops.gemm(ctx, self.s_wv2), self.s_wo2, bias=self.s_bo2, out_f32=True)      # attn2 == const/frame
+        v2, v2t_c = self._attn2_const(ctx, tctx if tctx_tokens is None else None)                    # attn2 == const/frame
         h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h)
         n3 = ops.layernorm(h, *self.s_ln["norm3"])
         g = ops.gemm(n3, self.s_wf1, bias=self.s_bf1, geglu=True)
@@ -350,7 +371,7 @@ class SpatialVideoTransformer:
         at = torch.empty((B * T * pt, c), dtype=x.dtype, device=x.device)
         ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pt, heads)
         if tctx_tokens is None:
-            v2t = ops.gemm(ops.gemm(tctx, self.t_wv2), self.t_wo2, bias=self.t_bo2, out_f32=True)    # [B, C]
+            v2t = v2t_c                                                                               # [B, C]
             xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm)
         else:
             # APM: attn2 of the temporal block is a real cross-attention of every (frame, pixel) token to the n_tok context tokens of its
@@ -537,11 +558,26 @@ class _EncoderBase:
         emb = self.label_emb.forward(ops.to_bf16(y), add=emb)      # emb + label_emb(y)
         return ops.to_bf16(emb, silu=True)                          # every emb_layers starts with SiLU
 
+    def _pack_emb_layers(self):
+        """Every ResBlock (and its time_stack twin) starts its `emb_layers` with SiLU + Linear(emb -> cout) of the SAME timestep embedding
+        (openaimodel.py:328-354): ~90 GEMMs of 50 rows per UNet forward, each a launch that streams 0.8-3.3 MB of weights through 5-20
+        workgroups (20 us for 1 us of HBM time; 1.2 % of the stage-1 job, round-2 kernel trace).  Their weights are stacked along N here
+        and the forward does ONE GEMM [frames, sum cout]; a block's result is a column slice of it (the GEMM's per-row-group vector operand
+        takes a leading dimension).  Bit-identical: every output element sees the same K walk."""
+        off, ws, bs = 0, [], []
+        for m in self._modules():
+            if isinstance(m, VideoResBlock):
+                m.e_off, m.et_off = off, off + m.cout
+                ws += [m.we, m.twe]; bs += [m.be, m.tbe]          # the block keeps its own copies: a block used on its own (tests) still works
+                off += 2 * m.cout
+        self._emb_w, self._emb_b = torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()
+
     @staticmethod
     def _run(layers, h, emb_silu, ctx, tctx, F, T, H, W, sp=None, emb_full=None):
+        """emb_silu / emb_full: rows of the local / of all frames of the PACKED emb_layers output (see _local_conditioning)."""
         for m in layers:
             if isinstance(m, VideoResBlock):
-                h = m.forward(h, emb_silu, F, T, H, W, sp=sp, emb_full=emb_full)
+                h = m.forward(h, None, F, T, H, W, sp=sp, emb_out=(emb_silu, emb_full))
             elif isinstance(m, SpatialVideoTransformer):
                 h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp)
             else:
@@ -549,14 +585,21 @@ class _EncoderBase:
         return h, H, W
 
     def _local_conditioning(self, timesteps, context, y, T, sp):
-        """(emb of this rank's frames, emb of all frames, per-frame context of this rank's frames, per-video context, local frame count).
+        """(packed emb_layers output of this rank's frames, of all frames, per-frame context of this rank's frames, per-video context, local frame count).
         timesteps / context / y always describe ALL B*T frames (they are tiny); `sp` selects this rank's rows."""
         emb_full = self._embed(timesteps, y)
-        ctx, tctx = self._contexts(context, T)
+        emb_full = ops.gemm(emb_full, self._emb_w, bias=self._emb_b, out_f32=True)      # all blocks' emb_layers at once (_pack_emb_layers)
+        B = timesteps.numel() // T
+        # one `context` tensor -> one (ctx, tctx) pair: the Euler steps of a chunk pass the same tensor object, and the transformer blocks key
+        # their per-chunk cross-attention constants on the identity of what they receive here
+        cc = getattr(self, "_ctx_cache", None)
+        if cc is None or cc[0] is not context or cc[1] != context._version or cc[2] != (T, id(sp), ops.ELEM):
+            ctx, tctx = self._contexts(context, T)
+            self._ctx_cache = cc = (context, context._version, (T, id(sp), ops.ELEM), ctx if sp is None else sp.take_frames(ctx, B, T), tctx, sp)
+        ctx, tctx = cc[3], cc[4]
         if sp is None:
             return emb_full, emb_full, ctx, tctx, timesteps.numel()
-        B = timesteps.numel() // T
-        return sp.take_frames(emb_full, B, T), emb_full, sp.take_frames(ctx, B, T), tctx, B * sp.frame_counts(T)[sp.rank]
+        return sp.take_frames(emb_full, B, T), emb_full, ctx, tctx, B * sp.frame_counts(T)[sp.rank]
 
     def _contexts(self, context, T):
         """(per-frame context, per-video context = context[::T]).  One CLIP token per frame (the shipped configuration): 16-bit [F, ctx_dim] /
@@ -634,6 +677,7 @@ class VideoUNet(_EncoderBase):
         for m in self._modules():
             m.prepare(sd, device)
         self.ow, self.ob = _dev_f32(sd["out.0.weight"], device), _dev_f32(sd["out.0.bias"], device)
+        self._pack_emb_layers()
         self.device = device
         self.prepared = True
         return self
@@ -762,6 +806,7 @@ class ControlNet(_EncoderBase):
         check_state_dict(self.spec(), sd)
         for m in self._modules():
             m.prepare(sd, device)
+        self._pack_emb_layers()
         self.device = device
         self.prepared = True
         return self

@@ -42,7 +42,12 @@ class StreamingWrapper:
 
             x_ctrl = reduce_rows(x_tok, pix)
             t_ctrl = reduce_rows(t, 1)
-            ctx_ctrl = reduce_rows(context[:, :1], 1)                 # only CLIP token 0 (wrappers.py:39)
+            # only CLIP token 0 (wrappers.py:39).  One derived tensor per `context` OBJECT: the networks recognise a chunk's constant context by
+            # identity and compute its cross-attention constants once per chunk instead of once per Euler step (video_model._attn2_const)
+            held = getattr(self, "_ctx_ctrl", None)
+            if held is None or held[0] is not context or held[1] != context._version or held[2] != (batch_size, T, Tc):
+                self._ctx_ctrl = held = (context, context._version, (batch_size, T, Tc), reduce_rows(context[:, :1], 1))
+            ctx_ctrl = held[3]
             y_ctrl = reduce_rows(y, 1)
             # ... and the pixel-space control frames, repeated for both CFG halves (wrappers.py:45-48)
             # "(2 B) F ..." in the reference (B = 1 video, CFG batch 2); one copy per batch element here so that a rank

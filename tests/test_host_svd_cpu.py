@@ -90,6 +90,33 @@ def test_two_videos_through_one_wrapper_do_not_share_control_state(tiny):
             assert torch.equal(got, fresh)
 
 
+def test_per_chunk_context_constants_follow_the_context_tensor(tiny):
+    """The one-token cross-attention constants (video_model._attn2_const) and the derived context tensors are cached per context OBJECT: the
+    same object twice must hit (bit-equal output), a new object with other values -- or the same object modified in place -- must not."""
+    tu = tiny["tu"]
+    inp = tiny["cases"].tiny_wrapper_inputs()
+    kw = dict(batch_size=2, num_video_frames=tu["T"], image_only_indicator=torch.zeros(2, tu["T"]), ctrl_frames=inp["ctrl_frames"])
+    from streamingt2v_amd.video_model import ControlNet, VideoUNet
+    from streamingt2v_amd.wrappers import StreamingWrapper
+
+    def fresh(c):
+        u, cn = VideoUNet(tiny["unet"].cfg), ControlNet(tiny["unet"].cfg)
+        u.load_state_dict(tiny["sd_u"], device="cpu"); cn.load_state_dict(tiny["sd_c"], device="cpu")
+        return StreamingWrapper(u, cn, tu["Tc"]).forward(inp["x"], inp["t"], c, **kw)
+
+    with torch.no_grad():
+        c1 = {k: inp[k].float().contiguous() for k in ("concat", "crossattn", "vector")}
+        a = tiny["wrap"].forward(inp["x"], inp["t"], c1, **kw)
+        b = tiny["wrap"].forward(inp["x"], inp["t"], c1, **kw)                       # same objects: cache hits
+        assert torch.equal(a, b) and torch.equal(a, fresh(c1))
+        c2 = dict(c1, crossattn=(c1["crossattn"] * -0.5 + 0.25).contiguous())         # the next video's context
+        d = tiny["wrap"].forward(inp["x"], inp["t"], c2, **kw)
+        assert torch.equal(d, fresh(c2)) and not torch.equal(d, a)
+        c2["crossattn"].mul_(2.0)                                                      # in place: same object, new version
+        e = tiny["wrap"].forward(inp["x"], inp["t"], c2, **kw)
+        assert torch.equal(e, fresh(c2)) and not torch.equal(e, d)
+
+
 def test_apm_block_host_logic_vs_reference_golden(monkeypatch, golden_dir):
     """Appearance-preservation module (use_apm: true; attention.py:596-620): SpatialVideoTransformer on a 17-token context -- the spatial
     block's Conv1d + LayerNorm + gate front (as a GEMM on an im2col of the CLIP axis) and the temporal block's real cross-attention to the
