@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
 // ------------------------------------------------------------------------------------------------------------
 // Bound: NOT HBM.  Per (pixel, head) this VALU form does 2 * T * T * 64 fp32 FMAs and re-reads every K / V row from LDS once per query
 // lane: measured 1.5-1.8 TB/s of algorithmic traffic.  Sequences of <= 32 frames (all of StreamingSVD's: 25 x 25, CAM 25 x 7) now go to
-// attn_temporal_mfma32_kernel below (4.5-5.0 TB/s, profiles/r02_attn_temporal_mfma_vs_valu.txt); this kernel serves the longer windows of
+// attn_temporal_mfma_kernel below (4.5-5.0 TB/s, profiles/r02_attn_temporal_mfma_vs_valu.txt); this kernel serves the longer windows of
 // the enhancer and stays selectable for T <= 32 as the A/B reference (SVD_ATTN_TEMPORAL_VALU=1).
 // Three instantiations: <32 keys, 32 lanes, 8 problems per workgroup> (SVD: 25 frames, CAM 25 x 7), <64, 64, 4> (the enhancer's
 // 38-frame windows) and <128, 64, 2> (the enhancer without blending: ONE window of up to 128 frames, the reference's default
@@ -416,7 +416,8 @@ extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Per-pixel temporal attention on the matrix cores, sequences <= 32 frames (SVD: 25 x 25; CAM: 25 queries x <= 32 keys), head dim 64.
+// Per-pixel temporal attention on the matrix cores, sequences <= 64 frames (SVD: 25 x 25; CAM: 25 queries x <= 32 keys; the enhancer's
+// 38-frame windows as two 32-key blocks), head dim 64.
 // One wave per (batch, pixel, head) problem, no workgroup-level synchronisation:
 //   S^T = K Q^T   4 MFMA 32x32x16: A = K rows, B = Q rows, both read straight from the token layout in fragment layout (lane = row
 //                 l31, 16 B at d = 16 ks + 8 hi) -- no LDS; the lane ends up with ITS query's 16 scores (keys (r%4) + 4 hi + 8 (r/4)),
@@ -432,130 +433,158 @@ extern "C" int svd_attn_spatial_d64(const svd_bf16* Q, int64_t ldq, const svd_bf
 // The next problem's 12 KB are requested before the current one is computed (registers), 8 waves per CU.
 // ------------------------------------------------------------------------------------------------------------
 namespace {
-template <class E, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_temporal_mfma32_kernel(
+// NKB = 32-key blocks (sequences <= 32 NKB frames; queries run in blocks of 32 against the same K / V).  NKB = 1 also keeps the NEXT problem's
+// 12 KB in flight in registers; NKB = 2 (the enhancer's 38-frame windows) has no registers left for that and relies on 8 waves per CU.
+template <class E, int NW, int NKB>
+__global__ __launch_bounds__(NW * 64) void attn_temporal_mfma_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ V, int64_t ldv, svd_bf16* __restrict__ O, int64_t ldo,
     int batch, int tq, int tk, int n_pix, int heads, int64_t n_prob) {
     constexpr int VROW = 144;      // bytes per staged row: 128 + 16, so that the two half-waves of a 2-byte gather (rows 4 apart) use different banks
+    constexpr bool PREFETCH = NKB == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    char* const sV = smem + wave * (32 * VROW);
-    // per-lane row offsets (elements): fragment rows are clamped to the last real frame (masked / discarded later)
+    constexpr int WAVE_ROWS = NKB == 1 ? 32 : 32 * NKB + 32;      // V tile (+ 32 staging rows for O when the V tile must outlive a query block)
+    char* const sV = smem + wave * (WAVE_ROWS * VROW);
     const int64_t qstep = (int64_t)n_pix * ldq, kstep = (int64_t)n_pix * ldk, vstep = (int64_t)n_pix * ldv, ostep = (int64_t)n_pix * ldo;
-    const int64_t q_lane = (int64_t)(l31 < tq ? l31 : tq - 1) * qstep + 8 * hi;
-    const int64_t k_lane = (int64_t)(l31 < tk ? l31 : tk - 1) * kstep + 8 * hi;
     const int nrow = lane >> 3, nchk = lane & 7;          // natural (row-major) view of a [32][64] tile: row nrow + 8 i, 16-byte chunk nchk
-    struct Tile { uint4 q[4], k[4], v[4]; };
+    const int nqb = (tq + 31) >> 5;                       // query blocks of this problem size (<= NKB)
+    struct Tile { uint4 q[NKB][4], k[NKB][4], v[4 * NKB]; };
     struct Where { int b, px, h; };                       // 32-bit problem arithmetic (the launcher guarantees n_prob < 2^31): 64-bit scalar divisions cost ~100 SALU each
     auto where = [&](int prob) __attribute__((always_inline)) -> Where {
         const int bp = prob / heads;
         Where w; w.h = prob - bp * heads; w.b = bp / n_pix; w.px = bp - w.b * n_pix;
         return w;
     };
+    // fragment rows are clamped to the last real frame (masked / discarded later)
     auto load = [&](const Where& w, Tile& t) __attribute__((always_inline)) {
-        const svd_bf16* q0 = Q + ((int64_t)w.b * tq * n_pix + w.px) * ldq + w.h * 64 + q_lane;
-        const svd_bf16* k0 = K + ((int64_t)w.b * tk * n_pix + w.px) * ldk + w.h * 64 + k_lane;
+        const svd_bf16* q0 = Q + ((int64_t)w.b * tq * n_pix + w.px) * ldq + w.h * 64 + 8 * hi;
+        const svd_bf16* k0 = K + ((int64_t)w.b * tk * n_pix + w.px) * ldk + w.h * 64 + 8 * hi;
         const svd_bf16* v0 = V + ((int64_t)w.b * tk * n_pix + w.px) * ldv + w.h * 64 + nchk * 8;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { t.q[ks] = *(const uint4*)(q0 + 16 * ks); t.k[ks] = *(const uint4*)(k0 + 16 * ks); }
+        for (int blk = 0; blk < NKB; ++blk) {
+            int rq = 32 * blk + l31, rk = 32 * blk + l31;
+            if (rq > tq - 1) rq = tq - 1;
+            if (rk > tk - 1) rk = tk - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int ks = 0; ks < 4; ++ks) {
+                t.q[blk][ks] = *(const uint4*)(q0 + (int64_t)rq * qstep + 16 * ks);
+                t.k[blk][ks] = *(const uint4*)(k0 + (int64_t)rk * kstep + 16 * ks);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * NKB; ++i) {
             int r = nrow + 8 * i;
             if (r > tk - 1) r = tk - 1;                   // finite filler: those keys get probability exactly 0
             t.v[i] = *(const uint4*)(v0 + (int64_t)r * vstep);
         }
     };
     const float c = 0.125f * 1.44269504088896341f;        // d^-0.5 * log2(e)
-    const int klim = tk - 4 * hi;                         // key of register r is kb(r) + 4 hi with kb(r) = (r & 3) + 8 (r >> 2): real iff kb(r) < klim
+    const int klim = tk - 4 * hi;                         // key of register r of block kb is 32 kb + kr(r) + 4 hi, kr(r) = (r & 3) + 8 (r >> 2): real iff 32 kb + kr(r) < klim
 
     Tile cur;
     const int nprob = (int)n_prob, stride = (int)gridDim.x * NW;
     int prob = (int)blockIdx.x * NW + wave;
     Where wc = where(prob < nprob ? prob : 0);
-    if (prob < nprob) load(wc, cur);
+    if (PREFETCH && prob < nprob) load(wc, cur);
     for (; prob < nprob; prob += stride) {
         Tile nxt;
         const bool more = prob + stride < nprob;          // wave-uniform
         const Where wn = where(more ? prob + stride : 0);
-        if (more) load(wn, nxt);
+        if constexpr (PREFETCH) { if (more) load(wn, nxt); }
+        else load(wc, cur);
         // ---- V rows -> LDS (row-major)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(uint4*)(sV + (nrow + 8 * i) * VROW + nchk * 16) = cur.v[i];
+        for (int i = 0; i < 4 * NKB; ++i) *(uint4*)(sV + (nrow + 8 * i) * VROW + nchk * 16) = cur.v[i];
         __builtin_amdgcn_wave_barrier();
-        // ---- S^T = K Q^T
-        f32x16_t s_acc;
+        svd_bf16* const o0 = O + ((int64_t)wc.b * tq * n_pix + wc.px) * ldo + wc.h * 64 + nchk * 8;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
+        for (int qb = 0; qb < NKB; ++qb) {
+            if (qb < nqb) {                               // wave-uniform
+                // ---- S^T = K Q^T : NKB key blocks x this query block
+                f32x16_t s_acc[NKB];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s_acc = E::mfma(cur.k[ks], cur.q[ks], s_acc);
-        // ---- softmax of the lane's query over its 16 keys + the 16 of lane ^ 32
-        float mx = -INFINITY;
+                for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kb = (r & 3) + 8 * (r >> 2);
-            s_acc[r] = (kb < klim) ? s_acc[r] : -INFINITY;
-            mx = fmaxf(mx, s_acc[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mneg = -mx * c;
-        float psum = 0.f;
-        uint32_t pk[8];
+                    for (int i = 0; i < 16; ++i) s_acc[kb][i] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(s_acc[r], c, mneg)), p1 = __builtin_amdgcn_exp2f(fmaf(s_acc[r + 1], c, mneg));
-            psum += p0 + p1;
-            pk[r >> 1] = E::pack(p0, p1);
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        const float inv = 1.f / psum;
-        // ---- O^T = V^T P^T : element e of the A fragment of k-step s2 is key 16 s2 + 8 (e >> 2) + (e & 3) + 4 hi -- the key of P register 8 s2 + e
-        f32x16_t o_acc[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o_acc[0][i] = 0.f; o_acc[1][i] = 0.f; }
-        const uint16_t* vb = (const uint16_t*)(sV + 4 * hi * VROW) + l31;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            uint4 pf;
-            pf.x = pk[4 * s2 + 0]; pf.y = pk[4 * s2 + 1]; pf.z = pk[4 * s2 + 2]; pf.w = pk[4 * s2 + 3];
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                uint32_t w[4];
-#pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    const int e = 2 * e2;
-                    const int key0 = 16 * s2 + 8 * (e >> 2) + (e & 3), key1 = key0 + 1;
-                    const uint32_t lo = vb[key0 * (VROW / 2) + 32 * db], hi16 = vb[key1 * (VROW / 2) + 32 * db];
-                    w[e2] = lo | (hi16 << 16);
+                    for (int ks = 0; ks < 4; ++ks) s_acc[kb] = E::mfma(cur.k[kb][ks], cur.q[qb][ks], s_acc[kb]);
                 }
-                uint4 vf; vf.x = w[0]; vf.y = w[1]; vf.z = w[2]; vf.w = w[3];
-                o_acc[db] = E::mfma(vf, pf, o_acc[db]);
+                // ---- softmax of the lane's query over its 16 NKB keys + the 16 NKB of lane ^ 32
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kr = 32 * kb + (r & 3) + 8 * (r >> 2);
+                        s_acc[kb][r] = (kr < klim) ? s_acc[kb][r] : -INFINITY;
+                        mx = fmaxf(mx, s_acc[kb][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mneg = -mx * c;
+                float psum = 0.f;
+                uint32_t pk[NKB][8];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float p0 = __builtin_amdgcn_exp2f(fmaf(s_acc[kb][r], c, mneg)), p1 = __builtin_amdgcn_exp2f(fmaf(s_acc[kb][r + 1], c, mneg));
+                        psum += p0 + p1;
+                        pk[kb][r >> 1] = E::pack(p0, p1);
+                    }
+                psum += __shfl_xor(psum, 32, 64);
+                const float inv = 1.f / psum;
+                // ---- O^T = V^T P^T : element e of the A fragment of k-step s2 of key block kb is key 32 kb + 16 s2 + 8 (e >> 2) + (e & 3) + 4 hi --
+                //      the key of P register 8 s2 + e of that block
+                f32x16_t o_acc[2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o_acc[0][i] = 0.f; o_acc[1][i] = 0.f; }
+                const uint16_t* vb = (const uint16_t*)(sV + 4 * hi * VROW) + l31;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        uint4 pf;
+                        pf.x = pk[kb][4 * s2 + 0]; pf.y = pk[kb][4 * s2 + 1]; pf.z = pk[kb][4 * s2 + 2]; pf.w = pk[kb][4 * s2 + 3];
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            uint32_t w[4];
+#pragma unroll
+                            for (int e2 = 0; e2 < 4; ++e2) {
+                                const int e = 2 * e2;
+                                const int key0 = 32 * kb + 16 * s2 + 8 * (e >> 2) + (e & 3), key1 = key0 + 1;
+                                const uint32_t lo = vb[key0 * (VROW / 2) + 32 * db], hi16 = vb[key1 * (VROW / 2) + 32 * db];
+                                w[e2] = lo | (hi16 << 16);
+                            }
+                            uint4 vf; vf.x = w[0]; vf.y = w[1]; vf.z = w[2]; vf.w = w[3];
+                            o_acc[db] = E::mfma(vf, pf, o_acc[db]);
+                        }
+                    }
+                // ---- O rows: registers (query l31, d = 32 db + 8 g + 4 hi + 0..3) -> LDS -> whole 128-byte rows to HBM.  The staging rows follow
+                //      the V tile (NKB = 1: they ARE the V tile, every lane is done with it; NKB = 2: a second region, V stays for the next query block)
+                char* const sO = NKB == 1 ? sV : sV + 32 * NKB * VROW;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 o;
+                        o.x = E::pack(o_acc[db][4 * g + 0] * inv, o_acc[db][4 * g + 1] * inv);
+                        o.y = E::pack(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv);
+                        *(uint2*)(sO + l31 * VROW + (32 * db + 8 * g + 4 * hi) * 2) = o;
+                    }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = nrow + 8 * i;
+                    if (32 * qb + r < tq) *(uint4*)(o0 + (int64_t)(32 * qb + r) * ostep) = *(const uint4*)(sO + r * VROW + nchk * 16);
+                }
+                __builtin_amdgcn_wave_barrier();          // the staging rows are free again
             }
         }
-        // ---- O rows: registers (query l31, d = 32 db + 8 g + 4 hi + 0..3) -> LDS -> whole 128-byte rows to HBM
-        __builtin_amdgcn_wave_barrier();                  // every lane is done with the V tile
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 o;
-                o.x = E::pack(o_acc[db][4 * g + 0] * inv, o_acc[db][4 * g + 1] * inv);
-                o.y = E::pack(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv);
-                *(uint2*)(sV + l31 * VROW + (32 * db + 8 * g + 4 * hi) * 2) = o;
-            }
-        __builtin_amdgcn_wave_barrier();
-        {
-            svd_bf16* o0 = O + ((int64_t)wc.b * tq * n_pix + wc.px) * ldo + wc.h * 64 + nchk * 8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = nrow + 8 * i;
-                if (r < tq) *(uint4*)(o0 + (int64_t)r * ostep) = *(const uint4*)(sV + r * VROW + nchk * 16);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                  // the tile is free for the next problem's V rows
-        if (more) cur = nxt;
+        if constexpr (PREFETCH) { if (more) cur = nxt; }
         wc = wn;
     }
 }
@@ -571,13 +600,18 @@ extern "C" int svd_attn_temporal_d64(const svd_bf16* Q, int64_t ldq, const svd_b
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return SVD_EINVAL;
     const int64_t n_prob = (int64_t)batch * n_pix * heads;
     static const bool valu_only = getenv("SVD_ATTN_TEMPORAL_VALU") != nullptr;      // A/B switch: the pre-MFMA kernel for T <= 32
-    if (tq <= 32 && tk <= 32 && !valu_only && n_prob < ((int64_t)1 << 31) - 256 * 8 * 4) {
+    if (tq <= 64 && tk <= 64 && !valu_only && n_prob < ((int64_t)1 << 31) - 256 * 8 * 4) {
         constexpr int NW = 4;
         int64_t nb = (n_prob + NW - 1) / NW;
         if (nb > 256 * 8) nb = 256 * 8;
-        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_mfma32_kernel<E, NW>), dim3((unsigned)nb), dim3(NW * 64), NW * 32 * 144,
-                                                     (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
-        SVD_CHECK_LAUNCH("attn_temporal_mfma32");
+        if (tq <= 32 && tk <= 32) {
+            SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_mfma_kernel<E, NW, 1>), dim3((unsigned)nb), dim3(NW * 64), NW * 32 * 144,
+                                                         (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
+        } else {      // V tile of 64 rows + 32 staging rows for O per wave
+            SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_temporal_mfma_kernel<E, NW, 2>), dim3((unsigned)nb), dim3(NW * 64), NW * 96 * 144,
+                                                         (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo, batch, tq, tk, n_pix, heads, n_prob));
+        }
+        SVD_CHECK_LAUNCH("attn_temporal_mfma");
         return SVD_OK;
     }
     const int ng = (tq <= 32 && tk <= 32) ? 8 : (tk <= 64 ? 4 : 2);
