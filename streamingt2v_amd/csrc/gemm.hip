@@ -97,7 +97,22 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
     if (a.tile_cfg > 0 && a.a_mode == SVD_A_CONV3X3 && a.ups && svd_gemm_config_valid(args, cfg) != 1) cfg = pick_cfg(a);   // a tuned table from before the subset
     if (svd_gemm_config_valid(args, cfg) != 1) return SVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (a.dtype == SVD_DTYPE_BF16) return svd_gemm_launch_bf16(a, cfg, s);
-    if (a.dtype == SVD_DTYPE_F16) return svd_gemm_launch_f16(a, cfg, s);
+    // the tile table is instantiated in four parts per element type (gemm_cfg.h)
+    const bool f16 = a.dtype == SVD_DTYPE_F16;
+    if (!f16 && a.dtype != SVD_DTYPE_BF16) return SVD_EINVAL;
+    switch (cfg) {
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p0(a, cfg, s) : svd_gemm_launch_bf16_p0(a, cfg, s);
+        SVD_GEMM_CONFIGS_P0(X)
+#undef X
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p1(a, cfg, s) : svd_gemm_launch_bf16_p1(a, cfg, s);
+        SVD_GEMM_CONFIGS_P1(X)
+#undef X
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p2(a, cfg, s) : svd_gemm_launch_bf16_p2(a, cfg, s);
+        SVD_GEMM_CONFIGS_P2(X)
+#undef X
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p3(a, cfg, s) : svd_gemm_launch_bf16_p3(a, cfg, s);
+        SVD_GEMM_CONFIGS_P3(X)
+#undef X
+    }
     return SVD_EINVAL;
 }

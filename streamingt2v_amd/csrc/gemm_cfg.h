@@ -64,31 +64,42 @@ struct GemmCfg {
 
 // ---- configuration table ---------------------------------------------------------------------------------
 //        id  BM   BN   WM WN BK  GLDS   TRANS  NSTAGE
-#ifndef SVD_GEMM_CONFIGS   /* a test translation unit may predefine a reduced table */
-#define SVD_GEMM_CONFIGS(X)                                                                           \
-    X(1, 128, 128, 2, 2, 64, true, false, 2)  /* default: 4 waves, 64x64 per wave, 2 WG/CU            */ \
-    X(2, 256, 128, 4, 2, 64, true, false, 2)  /* 8 waves, 64x64 per wave                              */ \
-    X(3, 128, 64, 2, 2, 64, true, false, 2)   /* narrow N                                             */ \
-    X(4, 128, 320, 2, 2, 64, true, false, 2)  /* N = 320 / 960 exactly, 64x160 per wave               */ \
-    X(5, 128, 128, 2, 2, 32, true, false, 2)  /* K (or cin) multiple of 32 only                       */ \
-    X(6, 128, 128, 2, 2, 64, false, false, 2) /* register-staged fallback of 1                        */ \
-    X(7, 128, 128, 2, 2, 64, true, true, 2)   /* transposed output (V^T for attention)                */ \
-    X(8, 256, 256, 4, 2, 64, true, false, 2)  /* 8 waves, 64x128 per wave                             */ \
-    X(9, 128, 256, 2, 2, 64, true, false, 2)  /* 4 waves, 64x128 per wave                             */ \
-    X(10, 256, 128, 2, 2, 64, true, false, 2) /* 4 waves, 128x64 per wave                             */ \
-    X(11, 256, 256, 2, 2, 64, true, false, 2) /* 4 waves, 128x128 per wave (1 wave / SIMD)            */ \
-    X(12, 64, 128, 2, 2, 64, true, false, 2)  /* small M                                              */ \
-    X(13, 128, 160, 4, 1, 64, true, false, 2) /* N = 320 as 2 tiles, 32x160 per wave                  */ \
-    X(14, 256, 160, 4, 1, 64, true, false, 2) /* N = 320 as 2 tiles, 64x160 per wave                  */ \
-    X(15, 256, 64, 4, 1, 64, true, false, 2)  /* N = 320 as 5 tiles, 64x64 per wave                   */ \
-    X(16, 128, 192, 2, 2, 64, true, false, 2) /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */ \
-    X(17, 256, 256, 4, 2, 32, true, false, 3) /* 3-stage ring, BK 32: loads 2 K tiles ahead (133 KB)          */ \
-    X(18, 256, 128, 4, 2, 64, true, false, 3) /* 3-stage ring (144 KB)                                        */ \
-    X(19, 256, 128, 4, 2, 32, true, false, 4)  /* 4-stage ring, BK 32: requests 3 K tiles ahead (133 KB)                                  */ \
-    X(20, 256, 256, 2, 4, 64, true, false, 2)  /* 8 with 128x64 wave tiles                                                              */ \
-    X(21, 256, 320, 4, 2, 64, true, false, 2)  /* N = 320 k exactly (320 / 640 / 960 / 1280 ...), 8 waves, 64x160 per wave (157 KB)     */ \
-    X(22, 128, 320, 4, 2, 64, true, false, 2)  /* same, 32x160 per wave                                                                 */ \
-    X(23, 128, 256, 2, 2, 32, true, false, 2)  /* 4 waves, 64x128 per wave, BK 32: 58 KB -> TWO workgroups per CU (one's epilogue under the other's MFMAs) */
+// The table is split into four parts: every part is instantiated in its own pair of translation units (gemm_{bf16,f16}_p0..3.hip), so that the
+// 23 tiles x 4 views x 2 element types compile on 8 cores in parallel (one pair of units took 12 minutes).
+#ifndef SVD_GEMM_CONFIGS   /* a probe build may predefine a reduced table: it goes to part 0 */
+#define SVD_GEMM_CONFIGS_P0(X)                                                            \
+    X(1, 128, 128, 2, 2, 64, true, false, 2)       /* default: 4 waves, 64x64 per wave, 2 WG/CU            */ \
+    X(5, 128, 128, 2, 2, 32, true, false, 2)       /* K (or cin) multiple of 32 only                       */ \
+    X(9, 128, 256, 2, 2, 64, true, false, 2)       /* 4 waves, 64x128 per wave                             */ \
+    X(13, 128, 160, 4, 1, 64, true, false, 2)      /* N = 320 as 2 tiles, 32x160 per wave                  */ \
+    X(17, 256, 256, 4, 2, 32, true, false, 3)      /* 3-stage ring, BK 32: loads 2 K tiles ahead (133 KB)          */ \
+    X(21, 256, 320, 4, 2, 64, true, false, 2)      /* N = 320 k exactly (320 / 640 / 960 / 1280 ...), 8 waves, 64x160 per wave (157 KB)     */
+#define SVD_GEMM_CONFIGS_P1(X)                                                            \
+    X(2, 256, 128, 4, 2, 64, true, false, 2)       /* 8 waves, 64x64 per wave                              */ \
+    X(6, 128, 128, 2, 2, 64, false, false, 2)      /* register-staged fallback of 1                        */ \
+    X(10, 256, 128, 2, 2, 64, true, false, 2)      /* 4 waves, 128x64 per wave                             */ \
+    X(14, 256, 160, 4, 1, 64, true, false, 2)      /* N = 320 as 2 tiles, 64x160 per wave                  */ \
+    X(18, 256, 128, 4, 2, 64, true, false, 3)      /* 3-stage ring (144 KB)                                        */ \
+    X(22, 128, 320, 4, 2, 64, true, false, 2)      /* same, 32x160 per wave                                                                 */
+#define SVD_GEMM_CONFIGS_P2(X)                                                            \
+    X(3, 128, 64, 2, 2, 64, true, false, 2)        /* narrow N                                             */ \
+    X(7, 128, 128, 2, 2, 64, true, true, 2)        /* transposed output (V^T for attention)                */ \
+    X(11, 256, 256, 2, 2, 64, true, false, 2)      /* 4 waves, 128x128 per wave (1 wave / SIMD)            */ \
+    X(15, 256, 64, 4, 1, 64, true, false, 2)       /* N = 320 as 5 tiles, 64x64 per wave                   */ \
+    X(19, 256, 128, 4, 2, 32, true, false, 4)      /* 4-stage ring, BK 32: requests 3 K tiles ahead (133 KB)                                  */ \
+    X(23, 128, 256, 2, 2, 32, true, false, 2)      /* 4 waves, 64x128 per wave, BK 32: 58 KB -> TWO workgroups per CU (one's epilogue under the other's MFMAs) */
+#define SVD_GEMM_CONFIGS_P3(X)                                                            \
+    X(4, 128, 320, 2, 2, 64, true, false, 2)       /* N = 320 / 960 exactly, 64x160 per wave               */ \
+    X(8, 256, 256, 4, 2, 64, true, false, 2)       /* 8 waves, 64x128 per wave                             */ \
+    X(12, 64, 128, 2, 2, 64, true, false, 2)       /* small M                                              */ \
+    X(16, 128, 192, 2, 2, 64, true, false, 2)      /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */ \
+    X(20, 256, 256, 2, 4, 64, true, false, 2)      /* 8 with 128x64 wave tiles                                                              */
+#define SVD_GEMM_CONFIGS(X) SVD_GEMM_CONFIGS_P0(X) SVD_GEMM_CONFIGS_P1(X) SVD_GEMM_CONFIGS_P2(X) SVD_GEMM_CONFIGS_P3(X)
+#else
+#define SVD_GEMM_CONFIGS_P0(X) SVD_GEMM_CONFIGS(X)
+#define SVD_GEMM_CONFIGS_P1(X)
+#define SVD_GEMM_CONFIGS_P2(X)
+#define SVD_GEMM_CONFIGS_P3(X)
 #endif
 constexpr int kNumCfg = 23;
 
@@ -100,5 +111,6 @@ SVD_GEMM_CONFIGS(X)
 }  // namespace svd_gemm_detail
 
 // one per element type, defined in gemm_bf16.hip / gemm_f16.hip
-int svd_gemm_launch_bf16(const svd_gemm_args& a, int cfg, hipStream_t s);
-int svd_gemm_launch_f16(const svd_gemm_args& a, int cfg, hipStream_t s);
+#define SVD_GEMM_DECL_PART(P) int svd_gemm_launch_bf16_p##P(const svd_gemm_args& a, int cfg, hipStream_t s); int svd_gemm_launch_f16_p##P(const svd_gemm_args& a, int cfg, hipStream_t s);
+SVD_GEMM_DECL_PART(0) SVD_GEMM_DECL_PART(1) SVD_GEMM_DECL_PART(2) SVD_GEMM_DECL_PART(3)
+#undef SVD_GEMM_DECL_PART
