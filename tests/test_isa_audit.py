@@ -1,0 +1,59 @@
+"""CPU suite: static audit of the GEMM kernel's gfx950 ISA (tools/check_isa.py) -- the properties round 2's K-loop work rests on.  hipcc cross-compiles
+without a GPU; one tile (256x256, fp16) is compiled to assembly and its steady-state K loops are checked: a single basic block (one branch: the back
+edge), no scratch traffic, the expected MFMA / ds_read / LDS-DMA counts, no vector address arithmetic for the SADDR-form DMA of the plain view, and
+M0 written only by the DMA sequences (glds16_* do not restore it)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def listing(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "gemm_f16_cfg8.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm",
+           "-DSVD_GEMM_CONFIGS(X)=X(8,256,256,4,2,64,true,false,2)", "-S", "--cuda-device-only", "gemm_f16_p0.hip", "-o", str(out)]
+    subprocess.run(cmd, cwd=os.path.join(ROOT, "streamingt2v_amd", "csrc"), check=True, capture_output=True)
+    return out.read_text().splitlines()
+
+
+def test_k_loops_are_single_blocks_without_scratch(listing):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    kernels = list(check_isa.kernels(listing))
+    assert len(kernels) == 4                                     # plain, conv3x3, temporal3, conv3x3 with folded upsample
+    for name, body in kernels:
+        mode = int(re.search(r"EEELi(\d)E7ElemF16", name).group(1))
+        meta = {m.group(1): int(m.group(2)) for m in (re.match(r"^; (\w+): (\d+)", l) for l in body) if m}
+        assert meta["NumVgprs"] + meta.get("NumAgprs", 0) <= 256      # two waves per SIMD
+        m0_other = [l for l in body if re.search(r"\bm0\b", l) and not re.match(r"^\s+s_mov_b32 m0, s\d+", l)
+                    and "global_load_lds" not in l and not l.strip().startswith(";")]
+        assert not m0_other, m0_other[:3]
+        loops = []
+        for a, b in check_isa.loops(body):
+            ops = [l.split()[0] for l in body[a:b + 1] if re.match(r"^\s+[a-z]", l)]
+            mix = {}
+            for o in ops:
+                c = check_isa.classify(o)
+                mix[c] = mix.get(c, 0) + 1
+            if mix.get("mfma", 0):
+                loops.append(mix)
+        assert len(loops) == 2, loops                                # the loop that requests K tiles and the tail loop
+        fused, tail = loops
+        for mix in loops:
+            assert mix["mfma"] == 32 and mix["ds_read"] == 24 and mix["barrier"] == 1      # 4 k-steps x (2 x 4 MFMA, 6 fragment reads)
+            assert mix.get("scratch", 0) == 0
+            assert mix["branch"] == (1 if mode != 3 else mix["branch"]), (mode, mix)       # one basic block: only the back edge
+        assert fused["lds_dma"] == 8 and tail.get("lds_dma", 0) == 0
+        if mode == 0:
+            assert fused["valu"] <= 12, fused                        # SADDR DMA: nothing but the LDS fragment addresses
+        if mode in (1, 2):
+            assert fused["valu"] <= 34, fused                        # 4 x (offset add, mask test, two selects) for the view's A rows
