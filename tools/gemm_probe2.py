@@ -1,7 +1,10 @@
 """A/B of GEMM tile configurations on the job's dominant signatures (plain + implicit-GEMM conv), interleaved in ONE process
 (guide methodology rule 24): for every shape, every config is timed `reps` times round-robin; median and min reported.
    python tools/gemm_probe2.py 8,21,22,25 [reps]
-variants: full | no_epi (bit 27) | mfma_only (bits 30+27: no LDS-DMA, no epilogue) -- see gemm_impl.inc probe bits."""
+variants: full | no_epi (bit 27) | mfma_only (bits 30+27: no LDS-DMA, no epilogue) -- see gemm_impl.inc probe bits.  The probe bits exist only in builds made
+with -DSVD_GEMM_PROBES (make -C streamingt2v_amd/csrc gvariant NAME=probe PROBE_DEFS=-DSVD_GEMM_PROBES PV_CFGS=..., then SVD_LIB_FILE=libsvdhip_pv_probe.so);
+in the product library only the `full` column means anything -- and the switches themselves cost ~10 % of the K loop, so A/B decisions use probe-free
+variant builds (tools/probe_kloop.sh)."""
 import sys, os, ctypes as C, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from streamingt2v_amd import ops, lib as L
