@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- generated frames/sec of the StreamingSVD hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stage1|c2|ar_chunk|c3|enhance|vfi] [--dtype fp16|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stage1|c2|ar_chunk|c3|enhance|vfi|full] [--dtype fp16|bf16]
+    (--gpus N > 1 without a launcher re-executes itself as N ranks under torch.distributed.run; under a launcher it reads RANK / WORLD_SIZE)
 
 DEFAULT workload = stage 1 of the 200-frame job (BASELINE.json configs[2]; SURVEY.md 8d "stage-1 frames/s"): 100 diffusion-stage
 frames at 576x1024 = chunk 0 (25 frames, 25 Euler-EDM steps, no ControlNet) + 5 autoregressive chunks (30 AlignYourSteps steps,
@@ -13,6 +14,8 @@ chunk: the last AR chunk is cut by [:100], inference_i2v.py:190) / max-over-rank
   c2        BASELINE.json configs[1]: SVD-XT UNet single chunk, 25 frames, 25 steps, no ControlNet/CAM (parity-test case).
   ar_chunk  one autoregressive chunk repeated (30 AYS steps, ControlNet + CAM, decode 25 frames).
   c3        one step = a whole 100-frame stage-1 video.       enhance / vfi: the I2VGen-XL window pass / EMA-VFI.
+  full      BASELINE.json configs[4] / SURVEY 8d metric (ii): one step = one whole 200-frame job, stage 1 + enhancement with randomized
+            blending + frame interpolation; value = 200 final frames / end-to-end seconds, per-stage seconds in config.
 Weights: seeded random at the reference's exact architecture (no checkpoints offline; zero-inits un-zeroed).
 Inputs already resident in HBM when the timed region starts.
 Multi-GPU (--gpus N > 1, default --parallelism job): ONE job strong-scaled -- the two CFG halves over a rank pair (one RCCL
@@ -316,9 +319,15 @@ class Stage1Stream:
     (StreamingSVD.image_to_video + _autoregressive_generation, diffusion_trainer/streaming_svd.py:293-402, one chunk per step())."""
     KEPT = (25, 18, 18, 18, 18, 3)       # frames of each chunk that end up in video[:100] (inference_i2v.py:190)
 
-    def __init__(self, model, c, uc, noises):
+    def __init__(self, model, c, uc, noises, start=0, prev_frames=None):
+        """start: position in the 6-chunk cycle the first step() runs (bench: chosen so that the WARM-UP ends at a video boundary and the timed
+        region starts with chunk 0); a start inside a video needs `prev_frames` [>=7, 3, H, W], the stand-in for the decoded previous chunk
+        (used by warm-up steps only)."""
         self.model, self.c, self.uc, self.noises = model, c, uc, noises
-        self.i, self.chunks, self.video_u8 = 0, None, None
+        self.i, self.chunks, self.video_u8 = start % 6, None, None
+        if self.i:
+            assert prev_frames is not None
+            self.chunks = [prev_frames]
 
     def step(self):
         m, k = self.model, self.i % 6
@@ -336,9 +345,9 @@ class Stage1Stream:
         return self.KEPT[k]
 
 
-def run_stage1(args, rank, world, device):
-    """Default workload: stage 1 of the 200-frame job, one step = one chunk of the real autoregressive sequence (see the module docstring)."""
-    from streamingt2v_amd import ops, parallel
+def build_stage1(args, world, device):
+    """Models + chunk stream of the stage-1 workload under the job plan of this launch."""
+    from streamingt2v_amd import parallel
     from streamingt2v_amd.sampling import AlignYourSteps, EulerEDMSampler
     from streamingt2v_amd.streaming_svd import StreamingSVD
     plan = parallel.JobPlan.from_env(world, args.parallelism)          # CFG pair x sequence-parallel group (or replicas)
@@ -352,7 +361,20 @@ def run_stage1(args, rank, world, device):
     c, uc, _, _ = synthetic_inputs(device, 33 + plan.video_id)
     g = torch.Generator(device=device); g.manual_seed(133 + plan.video_id)
     noises = [torch.randn(T_FRAMES, 4, LAT_H, LAT_W, generator=g, device=device) for _ in range(6)]
-    stream = Stage1Stream(model, c, uc, noises)
+    return plan, model, c, uc, noises, g
+
+
+def run_stage1(args, rank, world, device):
+    """Default workload: stage 1 of the 200-frame job, one step = one chunk of the real autoregressive sequence (see the module docstring).
+    The warm-up ENDS at a video boundary (the stream starts (-warmup) mod 6 chunks into a video, on stand-in control frames), so the timed
+    region always begins with chunk 0; every step is bracketed by a device synchronisation so that chunk 0 and AR chunks are timed apart.
+    value = 100 frames / (mean chunk-0 time + 5 x mean AR-chunk time) of the timed steps: the whole-video rate, independent of where in the
+    6-chunk cycle the K timed steps happen to stop (frames-kept / time, which depends on it, is reported next to it)."""
+    from streamingt2v_amd import ops, parallel
+    plan, model, c, uc, noises, g = build_stage1(args, world, device)
+    start = (-args.warmup) % 6
+    prev = (torch.rand(7, 3, 8 * LAT_H, 8 * LAT_W, generator=g, device=device) * 2 - 1) if start else None
+    stream = Stage1Stream(model, c, uc, noises, start=start, prev_frames=prev)
 
     def sync_all():
         torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
@@ -361,12 +383,27 @@ def run_stage1(args, rank, world, device):
         stream.step()
     sync_all()
     t0 = time.perf_counter()
-    kept = 0
+    kept, t_prev, per_type = 0, t0, {0: [], 1: []}
     for _ in range(args.steps):
+        k = stream.i % 6
         kept += stream.step()
+        torch.cuda.synchronize()
+        t_now = time.perf_counter()
+        per_type[0 if k == 0 else 1].append(t_now - t_prev)
+        t_prev = t_now
     sync_all()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
     assert all(torch.isfinite(ch).all() for ch in stream.chunks)
+    mean = lambda v: sum(v) / len(v) if v else None
+    t_c0, t_ar = mean(per_type[0]), mean(per_type[1])
+    if world > 1:                                    # slowest rank per chunk type, like the total
+        t_c0 = parallel.max_over_ranks(t_c0, device=device) if t_c0 is not None else None
+        t_ar = parallel.max_over_ranks(t_ar, device=device) if t_ar is not None else None
+    kept_rate = plan.n_videos * kept / dt
+    if t_c0 is not None and t_ar is not None:
+        value, vdef = plan.n_videos * 100.0 / (t_c0 + 5.0 * t_ar), "100 frames / (mean chunk-0 s + 5 x mean AR-chunk s) of the timed steps"
+    else:
+        value, vdef = kept_rate, "frames kept / time (the timed steps hold only one chunk type: placement-dependent, use --steps >= 2)"
     roof = None
     if not args.no_trace and rank == 0 and world == 1:
         # separate traced pass: ONE AR chunk (the next chunk of the sequence if it is an AR chunk, else skip chunk 0 first)
@@ -386,19 +423,114 @@ def run_stage1(args, rank, world, device):
             except Exception as e:   # the GPU measurement above must never be lost to a host-side problem
                 cpu = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"FAILED: {e!r}"}
         print(json.dumps({
-            "metric": "generated frames/sec (576x1024)", "value": round(plan.n_videos * kept / dt, 4), "unit": "frames/s",
+            "metric": "generated frames/sec (576x1024)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": plan.scaling, "vs_baseline": None, "dtype": args.dtype.replace("fp16", "f16"), "data": "synthetic",
             "config": {"workload": "StreamingSVD 200-frame job, stage 1 (100 frames @576x1024, BASELINE configs[2]): one step = one chunk of the "
                                    "autoregressive sequence chunk 0 (25 EDM steps) | AR1..AR5 (30 AYS steps, ControlNet(7 decoded frames) + CAM), "
                                    "CFG 2 x 25 frames @ latent 72x128 per evaluation, temporal-VAE decode of every chunk",
-                       "frames_kept_per_chunk": list(Stage1Stream.KEPT), "frames_in_timed_steps": kept, "latent": [LAT_H, LAT_W],
-                       "denoise_steps": [args.denoise_steps or 25, args.denoise_steps or 30],
+                       "value_definition": vdef, "chunk0_s_mean": None if t_c0 is None else round(t_c0, 4), "ar_chunk_s_mean": None if t_ar is None else round(t_ar, 4),
+                       "chunks_timed": [len(per_type[0]), len(per_type[1])], "timed_region_starts_at": "chunk 0 (video boundary)",
+                       "frames_kept_per_chunk": list(Stage1Stream.KEPT), "frames_in_timed_steps": kept, "kept_frames_over_time": round(kept_rate, 4),
+                       "latent": [LAT_H, LAT_W], "denoise_steps": [args.denoise_steps or 25, args.denoise_steps or 30],
                        "parallelism": plan.describe(), "weights": "seeded random, reference architecture (1.59 B + 0.67 B + 64 M parameters)"},
             "roofline": roof, "cpu_baseline": cpu}))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def run_full(args, rank, world, device):
+    """--workload full (BASELINE configs[4], SURVEY 8d metric (ii)): one step = ONE whole 200-frame job, the script body of
+    code/inference_i2v.py:227-259 -- image_to_video (stage 1: chunk 0 + 5 AR chunks, 100 frames @576x1024, uint8) -> enhance_video
+    (frames resized to 720x1280, 2-D VAE encode, key-frame pre-pass, randomized blending: 3 windows of 38 frames, overlap 12, 29 DDIM
+    steps, CFG 9, per-frame VAE decode) -> interpolate_video (EMA-VFI, fast TTA, to 200 frames).  value = 200 final frames / end-to-end
+    seconds, host-side PIL resizes and device<->host copies between the stages included (they are part of the reference's job too).
+    Random-weight networks at the reference's architectures; the CLIP TEXT tower is replaced by fixed random prompt embeddings (it runs
+    once per job on two 77-token prompts).  --gpus N: stage 1 under the job plan, blending windows and VFI frame pairs sharded."""
+    import numpy as np
+    from streamingt2v_amd import parallel, pipeline as P
+    from streamingt2v_amd.clip_vision import ClipVisionConfig, OpenCLIPVisionTower
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    from streamingt2v_amd.enhance_codec import EnhanceCodec
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import AutoencoderKL2D, VaeConfig
+    plan, model, c, uc, noises, g = build_stage1(args, world, device)
+    eunet = I2VGenXLUNet(I2VConfig())
+    eunet.load_state_dict(init_by_name(eunet.spec(), seed=5, device=device), device=device)
+    vae2d = AutoencoderKL2D(VaeConfig())
+    vae2d.load_state_dict(init_by_name(vae2d.spec(), seed=21, device=device), device=device)
+    tower = OpenCLIPVisionTower(ClipVisionConfig())
+    tower.load_state_dict(init_by_name(tower.spec(), seed=22, device=device), device=device)
+    vfi = EMAVFI(VFIConfig())
+    vfi.load_state_dict(init_by_name(vfi.spec(), seed=3), device=device)
+    torch.cuda.empty_cache()
+    pipe = P.StreamingPipeline.__new__(P.StreamingPipeline)          # the stages are wired by hand: no checkpoint to load offline
+    pipe.cfg = dict(P.DEFAULTS, enhance_steps=args.denoise_steps or P.DEFAULTS["enhance_steps"])
+    pipe.model, pipe.enhancer_unet, pipe.vfi, pipe.device = model, eunet, vfi, device
+    pipe.group = None
+    if world > 1 and plan.mode == "job":
+        import torch.distributed as dist
+        pipe.group = dist.group.WORLD
+    ge = torch.Generator(); ge.manual_seed(1)
+    prompt = (torch.randn(1, 77, 1024, generator=ge), torch.randn(1, 77, 1024, generator=ge))
+    image = (np.random.RandomState(7).rand(576, 1024, 3) * 255).astype("uint8")
+    stage_s = {"stage1": 0.0, "enhance": 0.0, "vfi": 0.0}
+
+    def one():
+        with torch.no_grad():
+            t = time.perf_counter()
+            stream = Stage1Stream(model, c, uc, noises)
+            for _ in range(6):
+                stream.step()
+            video = stream.video_u8.cpu().numpy()                                   # uint8 [100, 576, 1024, 3], like trainer.generated_video
+            torch.cuda.synchronize(); t1 = time.perf_counter(); stage_s["stage1"] += t1 - t
+            torch.manual_seed(33)                                                   # image latents sample from the global stream (pipeline_i2vgen_xl.py:486)
+            codec = EnhanceCodec(vae2d, tower, generator=torch.Generator(device=device).manual_seed(8888), device=device)
+            codec.set_prompt_embeds(*prompt)
+            pipe.enhance_codec = codec
+            video = pipe.enhance_video(image=image, video=video, use_randomized_blending=True, chunk_size=38, overlap_size=12)
+            torch.cuda.synchronize(); t2 = time.perf_counter(); stage_s["enhance"] += t2 - t1
+            out = pipe.interpolate_video(video, dest_num_frames=200)
+            torch.cuda.synchronize(); stage_s["vfi"] += time.perf_counter() - t2
+            return video.shape[0], out
+
+    def sync_all():
+        torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one()
+    for k in stage_s:
+        stage_s[k] = 0.0
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_enh, out = one()
+    sync_all()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+    assert out.shape == (200, 720, 1280, 3) and str(out.dtype) == "uint8", (out.shape, out.dtype)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "final frames/sec (200-frame job, 720x1280 output)", "value": round(plan.n_videos * args.steps * 200 / dt, 4), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": plan.scaling, "vs_baseline": None, "dtype": args.dtype.replace("fp16", "f16"), "data": "synthetic",
+            "config": {"workload": "full pipeline (BASELINE configs[4]; inference_i2v.py:227-259): stage 1 (100 frames @576x1024) + I2VGen-XL enhancement with "
+                                   "randomized blending (3 windows x 38 frames, overlap 12, key-frame pre-pass, %d DDIM steps, CFG 9, 2-D VAE encode/decode @720x1280) "
+                                   "+ EMA-VFI to 200 frames" % len(pipe_timesteps(pipe)),
+                       "seconds_per_job": {k: round(v / args.steps, 2) for k, v in stage_s.items()}, "frames_after_enhancement": int(n_enh),
+                       "parallelism": plan.describe() + ("; blending windows and VFI frame pairs sharded over all ranks" if pipe.group is not None else ""),
+                       "weights": "seeded random, reference architectures (StreamingSVD 2.3 B, I2VGen-XL 1.42 B, AutoencoderKL, CLIP ViT-H/14 image tower, EMA-VFI 65.7 M); "
+                                  "CLIP text tower replaced by fixed random prompt embeddings"},
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def pipe_timesteps(pipe):
+    from streamingt2v_amd.enhance import DDIMSchedule
+    return DDIMSchedule().get_timesteps(pipe.cfg["enhance_steps"], pipe.cfg["enhance_strength"])
 
 
 def run_vfi(args, rank, world, device):
@@ -443,12 +575,28 @@ def run_vfi(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def self_spawn(n):
+    """`python bench.py --gpus N ...` without a launcher: run the same command line as N ranks of ONE node under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port) and pass its output / exit code through.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 6 = one whole video for stage1, 1 otherwise)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="stage1", choices=["stage1", "c2", "ar_chunk", "c3", "enhance", "vfi"])
+    ap.add_argument("--workload", default="stage1", choices=["stage1", "c2", "ar_chunk", "c3", "enhance", "vfi", "full"])
     ap.add_argument("--parallelism", default="job", choices=["job", "replica", "cfg"],
                     help="job (stage1): ONE job over all GPUs, CFG pair x frame<->pixel sequence parallelism (strong scaling); "
                          "replica: one video per GPU (weak scaling, no collective); cfg (c2 / ar_chunk): GPU pairs split the CFG halves of one video")
@@ -459,20 +607,30 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 6 if args.workload == "stage1" else 1
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        return self_spawn(args.gpus)        # `python bench.py --gpus N`: re-exec as N ranks under torch.distributed.run
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # SVD_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): every rank uses cuda:0 and the collectives go over gloo with host staging
+    share = os.environ.get("SVD_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     from streamingt2v_amd import ops, parallel
     from streamingt2v_amd.sampling import EulerEDMSampler
     from streamingt2v_amd.streaming_svd import StreamingSVD
-    parallel.init_from_env(backend="nccl", device=device)
+    parallel.init_from_env(backend="gloo" if share else "nccl", device=device)
     ops.set_element_dtype(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
     if args.workload == "stage1":
         return run_stage1(args, rank, world, device)
+    if args.workload == "full":
+        return run_full(args, rank, world, device)
     if args.workload == "enhance":
         return run_enhance(args, rank, world, device)
     if args.workload == "c3":

@@ -62,6 +62,7 @@ def blend_step_sharded(latents, denoise_chunk, chunk_size, overlap_size, n_chunk
     """Same step with the windows sharded round-robin over the ranks of `group` and one all-gather of the window
     outputs (each 4 x chunk x 90 x 160 fp16 = 4.4 MB at the shipped sizes).  Every rank returns the full latents."""
     import torch.distributed as dist
+    from . import parallel
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     starts = chunk_starts(latents.shape[2], chunk_size, overlap_size, n_chunks)
     offsets = draw_offsets(n_chunks, overlap_size, rng)          # identical on all ranks (same generator state)
@@ -75,6 +76,6 @@ def blend_step_sharded(latents, denoise_chunk, chunk_size, overlap_size, n_chunk
             mine.append(torch.zeros_like(latents[:, :, :chunk_size]).contiguous())
     send = torch.stack(mine, 0)                                    # [per_rank, B, C, chunk, H, W]
     recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    parallel.all_gather(recv, send, group=group)
     outs = [recv[idx % world][idx // world] for idx in range(n_chunks)]
     return _apply(torch.empty_like(latents), outs, starts, offsets, chunk_size)

@@ -79,11 +79,14 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
         } else return SVD_EINVAL;
     }
     if (a.K % 32 != 0) return SVD_EINVAL;
-    {   // the kernel's A-operand offsets are 32-bit ELEMENT offsets (gemm_impl.inc a_off / pix * lda): reject sources they cannot reach
+    if (a.a_mode != SVD_A_PLAIN) {   // the implicit-GEMM views address the source with 32-bit ELEMENT offsets (gemm_impl.inc a_off / pix * lda): reject sources they cannot reach
         int64_t src_rows = a.M;
         if (a.a_mode == SVD_A_CONV3X3) src_rows = (int64_t)(a.M / (a.hout * a.wout)) * a.hin * a.win + a.win + 2;   // + one row and column: offsets are taken from tap (1, 1)
         if (src_rows * a.lda >= ((int64_t)1 << 32)) return SVD_EINVAL;
+    } else {                         // plain A: 64-bit wave-uniform tile base + a 32-bit per-lane BYTE offset inside the tile's rows (at most 320 rows)
+        if ((int64_t)320 * a.lda * 2 >= ((int64_t)1 << 32)) return SVD_EINVAL;
     }
+    if ((int64_t)320 * a.ldw * 2 >= ((int64_t)1 << 32)) return SVD_EINVAL;      // W tiles: same SADDR form
     if (a.rowvec && a.rows_per_vec <= 0) return SVD_EINVAL;
     if (a.out_mode == SVD_OUT_BF16_T) {
         if (a.tok_per_frame <= 0 || a.tok_per_frame % 4 != 0 || a.M % a.tok_per_frame != 0 || a.tokens_ld % 4 != 0)

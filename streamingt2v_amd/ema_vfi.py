@@ -534,6 +534,7 @@ def vfi_process(video, vfi, video_len, out_size=(1280, 720), device="cuda", grou
     mid = lambda i: vfi.inference(bgr[i], bgr[i + 1], want_uint8=True)[1]
     if sharded and n_pairs > 0:
         import torch.distributed as dist
+        from . import parallel
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         per_rank = (n_pairs + world - 1) // world
         H, W = frames[0].shape[:2]
@@ -541,7 +542,7 @@ def vfi_process(video, vfi, video_len, out_size=(1280, 720), device="cuda", grou
                 for s in range(per_rank)]                                                                        # padded: equal contributions
         send = torch.stack(mine, 0).contiguous()
         recv = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(recv, send, group=group)
+        parallel.all_gather(recv, send, group=group)
         mids = [recv[i % world][i // world] for i in range(n_pairs)]
     else:
         mids = [mid(i) for i in range(n_pairs)]

@@ -13,7 +13,22 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""), os.environ.get("SVD_LIB_FILE", "libsvdhip.so")))   # probe / SVD_LIB_FILE: developer builds (reduced tile table, timing probes)
+
+
+def _lib_file():
+    """libsvdhip.so, or a developer build next to it (reduced tile table / timing probes): SVD_LIB=probe|probe2, or SVD_LIB_FILE=<basename>.
+    Only a plain file name of the form libsvdhip*.so INSIDE the package directory is accepted -- the variable can never make the package
+    dlopen an arbitrary path."""
+    import re
+    name = {"probe": "libsvdhip_probe.so", "probe2": "libsvdhip_probe2.so"}.get(os.environ.get("SVD_LIB", ""))
+    if name is None:
+        name = os.environ.get("SVD_LIB_FILE", "libsvdhip.so")
+        if not re.fullmatch(r"libsvdhip[A-Za-z0-9_.-]*\.so", name) or os.path.basename(name) != name or ".." in name:
+            raise ImportError(f"SVD_LIB_FILE={name!r}: only a file name matching libsvdhip*.so inside {_HERE} is accepted")
+    return name
+
+
+LIB_PATH = os.path.join(_HERE, _lib_file())
 
 ABI_VERSION = 5
 

@@ -17,18 +17,35 @@ F16 = torch.float16
 _DT = {torch.bfloat16: _l.DTYPE_BF16, torch.float16: _l.DTYPE_F16, torch.float32: _l.DTYPE_F32}
 
 # Element type new 16-bit tensors are created in when no 16-bit input exists to inherit it from (casts of fp32 inputs,
-# packed weights).  bf16 is the default; set_element_dtype(torch.float16) selects the reference's autocast precision.
-ELEM = torch.bfloat16
+# packed weights).  fp16 is the default: it is the reference's own autocast type (config.yaml:8 "16-mixed"), the type every parity
+# tolerance of tests/test_gpu_*parity*.py is asserted in and the type bench.py / __graft_entry__.smoke() run in (same MFMA rate as bf16,
+# 8x finer rounding).  set_element_dtype(torch.bfloat16) selects bf16 (~8x the fp16 deviation from the fp32 reference).
+DEFAULT_ELEM = torch.float16
+ELEM = DEFAULT_ELEM
 
 
-def set_element_dtype(dt):
+def set_element_dtype(dt=None):
+    """Select the 16-bit element type of everything created from here on (None: back to DEFAULT_ELEM).  Call it BEFORE load_state_dict:
+    packed weights keep the type they were packed in."""
     global ELEM
+    dt = DEFAULT_ELEM if dt is None else dt
     assert dt in (torch.bfloat16, torch.float16)
     ELEM = dt
 
 
 def _dt(t):
     return _DT[t.dtype]
+
+
+def tensor_version(t):
+    """In-place version counter of `t` for the per-chunk caches (video_model / wrappers key them on tensor IDENTITY + version), or None
+    when the tensor has none (tensors created under torch.inference_mode raise on ._version): None means "never a cache hit".
+    Contract of those caches: the same tensor OBJECT with the same version holds the same values -- writes through
+    .data / set_() do not bump the version and are not seen; call reset_caches() on the networks after such a write or between videos."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
 
 _zeros = {}
 _gn_ws = {}

@@ -33,7 +33,7 @@ def max_over_ranks(seconds, device="cpu"):
     """Job time = slowest rank (bench contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
 
@@ -41,6 +41,59 @@ def max_over_ranks(seconds, device="cpu"):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+# ---- collectives ---------------------------------------------------------------------------------------------------------------
+# Thin wrappers over torch.distributed used by every data-path exchange of the package.  With the "nccl" backend (= RCCL over xGMI on
+# ROCm) they are the plain collectives on device tensors.  With "gloo" and DEVICE tensors the payload is staged through host memory:
+# that is how the multi-process GPU tests run several ranks of the real HIP path on ONE leased GPU (RCCL refuses two ranks on the same
+# device) -- tests/test_gpu_multiproc.py.  Results are bit-identical either way (pure data movement; the fp64 sum of two numbers commutes).
+def _staged(t, group):
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather(parts, x, group=None):
+    x = x.contiguous()
+    if _staged(x, group):
+        hp = [torch.empty(p.shape, dtype=p.dtype) for p in parts]
+        dist.all_gather(hp, x.cpu(), group=group)
+        for p, h in zip(parts, hp):
+            p.copy_(h)
+    else:
+        dist.all_gather(parts, x, group=group)
+    return parts
+
+
+def all_to_all_single(recv, send, recv_splits, send_splits, group=None):
+    send = send.contiguous()
+    if _staged(send, group):
+        h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(h, send.cpu(), recv_splits, send_splits, group=group)
+        recv.copy_(h)
+    else:
+        dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group)
+    return recv
+
+
+def all_reduce_sum(t, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def broadcast(t, src, group=None):
+    """src: GLOBAL rank.  t must be contiguous (a slice along dim 0 of a contiguous tensor is)."""
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
 
 
 def shard_items(n_items, rank, world):
@@ -65,7 +118,7 @@ class CfgPairExchange:
 
     def gather(self, net_half):
         parts = [torch.empty_like(net_half), torch.empty_like(net_half)]
-        dist.all_gather(parts, net_half.contiguous(), group=self.group)
+        all_gather(parts, net_half, group=self.group)
         return torch.cat(parts, 0)
 
 
@@ -119,7 +172,7 @@ class SeqParallel:
         tl = cnt[self.rank]
         send = x.reshape(B, tl, S, pl, C).permute(2, 0, 1, 3, 4).contiguous()            # [dest][b][t_local][pixel_local][c]
         recv = torch.empty((B * T * pl, C), dtype=x.dtype, device=x.device)
-        dist.all_to_all_single(recv, send.reshape(-1, C), [B * c * pl for c in cnt], [B * tl * pl] * S, group=self.group)
+        all_to_all_single(recv, send.reshape(-1, C), [B * c * pl for c in cnt], [B * tl * pl] * S, group=self.group)
         if B == 1:
             return recv                                                                   # source order == frame order
         parts = recv.split([B * c * pl for c in cnt], 0)
@@ -136,13 +189,12 @@ class SeqParallel:
             xs = x.reshape(B, T, pl, C).split(cnt, 1)
             send = torch.cat([p.reshape(-1, C) for p in xs], 0)
         recv = torch.empty((S, B, tl, pl, C), dtype=x.dtype, device=x.device)             # [source = pixel range][b][t_local][pixel_local]
-        dist.all_to_all_single(recv.reshape(-1, C), send.contiguous(), [B * tl * pl] * S, [B * c * pl for c in cnt], group=self.group)
+        all_to_all_single(recv.reshape(-1, C), send, [B * tl * pl] * S, [B * c * pl for c in cnt], group=self.group)
         return recv.permute(1, 2, 0, 3, 4).reshape(B * tl * pix, C)
 
     # ---- small collectives ---------------------------------------------------------------------------------------------------------
     def allreduce_sums(self, sums):
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
-        return sums
+        return all_reduce_sum(sums, group=self.group)
 
     def gather_frames(self, x, B, T, per):
         """frame layout [B * Tl * per, C] of every rank -> all frames [B * T * per, C] on every rank (uneven ranges are padded to the
@@ -154,7 +206,7 @@ class SeqParallel:
         if tl < tmax:
             buf = torch.cat([buf, buf.new_zeros(B, (tmax - tl) * per, C)], 1)
         parts = [torch.empty_like(buf) for _ in range(self.size)]
-        dist.all_gather(parts, buf.contiguous(), group=self.group)
+        all_gather(parts, buf, group=self.group)
         return torch.cat([p[:, : c * per] for p, c in zip(parts, cnt)], 1).reshape(B * T * per, C)
 
 
@@ -167,27 +219,89 @@ class JobPlan:
     is sharded by its independent 8-frame groups over all ranks (broadcast of each group's frames from its owner).
     Amdahl: the Euler update, conditioning glue and the per-chunk hand-over are replicated (< 1 % of a chunk)."""
 
-    def __init__(self, world=1, rank=0, mode="job"):
+    def __init__(self, world=1, rank=0, mode="job", frames_cond=7, min_pix=144, preflight=True):
+        """frames_cond: conditioning frames of the ControlNet (the sequence-parallel degree cannot exceed it: every rank needs at least one);
+        min_pix: pixels of the LOWEST UNet level (9 x 16 at the 72 x 128 latent; the pixel layout splits them evenly).  A plan that the
+        shapes cannot carry is refused HERE, with the reason, instead of as an assert deep inside a forward.  preflight: run one tiny
+        instance of every collective the plan uses (uneven all-to-all, padded all-gather, fp64 all-reduce, broadcast) before any model is
+        built; a backend that cannot do them makes the plan fall back to replicas (`fallback_reason` says why) instead of dying mid-job."""
         self.world, self.rank, self.mode = world, rank, mode
         self.cfg_exchange, self.sp, self.n_videos, self.video_id = None, None, 1, 0
         self.decode_group = None
+        self.fallback_reason = None
         if world == 1:
             return
-        if mode == "replica":
+        if mode == "job":
+            why = self.validate(world, frames_cond, min_pix)
+            if why is not None:
+                self.mode, self.fallback_reason = "replica", why
+        if self.mode == "replica":
             self.n_videos, self.video_id = world, rank
             return
-        assert world % 2 == 0, "--parallelism job needs an even number of GPUs (CFG pair x sequence parallelism)"
         pairs = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]           # every rank creates every group, same order
         halves = [dist.new_group(list(range(h, world, 2))) for h in (0, 1)] if world > 2 else [None, None]
         self.cfg_exchange = CfgPairExchange(pairs[rank // 2])
         if world > 2:
             self.sp = SeqParallel(halves[rank % 2])
         self.decode_group = dist.group.WORLD
+        if preflight:
+            why = self._preflight()
+            if why is not None:          # every rank reaches the same verdict (the check ends in an all-reduce of the failure flags)
+                self.mode, self.fallback_reason = "replica", why
+                self.cfg_exchange = self.sp = self.decode_group = None
+                self.n_videos, self.video_id = world, rank
+
+    @staticmethod
+    def validate(world, frames_cond=7, min_pix=144):
+        """None if `world` ranks can share one job, else the reason (shown in the bench line)."""
+        if world % 2:
+            return f"job parallelism needs an even number of GPUs (CFG pair x sequence parallelism), got {world}"
+        sp = world // 2
+        if sp > frames_cond:
+            return f"sequence-parallel degree {sp} exceeds the {frames_cond} conditioning frames of the ControlNet (max {2 * frames_cond} GPUs)"
+        if sp > 1 and min_pix % sp:
+            return f"the lowest UNet level has {min_pix} pixels per frame, not divisible by the sequence-parallel degree {sp}"
+        return None
+
+    def _preflight(self):
+        """One tiny instance of every collective of the plan on the device the job will use.  Returns None or the failure text."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        err = None
+        try:
+            net = torch.full((4, 4), float(self.rank), device=dev)
+            got = self.cfg_exchange.gather(net)
+            assert got.shape == (8, 4)
+            if self.sp is not None:
+                sp, T, pix, C = self.sp, 2 * self.sp.size + 1, 2 * self.sp.size, 8
+                lo, hi = sp.frame_range(T)
+                full = torch.arange(T * pix * C, dtype=torch.float32, device=dev).reshape(T * pix, C).to(torch.float16)
+                mine = sp.take_frames(full, 1, T, pix)
+                back = sp.to_frames(sp.to_pixels(mine, 1, T, pix), 1, T, pix)
+                assert torch.equal(back, mine), "all-to-all round trip"
+                assert torch.equal(sp.gather_frames(mine, 1, T, pix), full), "padded all-gather"
+                sums = sp.allreduce_sums(torch.ones((1, 32, 2), dtype=torch.float64, device=dev))
+                assert float(sums[0, 0, 0]) == sp.size, "fp64 all-reduce"
+            t = torch.full((3, 5), float(self.rank), device=dev)
+            broadcast(t, src=0, group=self.decode_group)
+            assert float(t[0, 0]) == 0.0, "broadcast"
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+        except Exception as e:                      # noqa: BLE001 -- whatever the backend throws, the job must still produce a number
+            err = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([0.0 if err is None else 1.0], device="cpu" if dist.get_backend() == "gloo" else dev)
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = flag.item() > 0
+        except Exception as e:                      # noqa: BLE001
+            failed, err = True, err or f"{type(e).__name__}: {e}"
+        if not failed:
+            return None
+        return "job-plan collective preflight failed on " + (f"this rank: {err}" if err else "another rank")
 
     @classmethod
-    def from_env(cls, world, mode):
+    def from_env(cls, world, mode, **kw):
         rank = dist.get_rank() if (dist.is_initialized() and world > 1) else 0
-        return cls(world, rank, mode)
+        return cls(world, rank, mode, **kw)
 
     @property
     def scaling(self):
@@ -204,7 +318,8 @@ class JobPlan:
         if self.world == 1:
             return "single GPU"
         if self.mode == "replica":
-            return f"replica-per-gpu x{self.world} (independent videos, no data-path collective)"
+            why = f"; fell back from the one-job plan: {self.fallback_reason}" if self.fallback_reason else ""
+            return f"replica-per-gpu x{self.world} (independent videos, no data-path collective{why})"
         sp = self.sp.size if self.sp else 1
         return (f"one job over {self.world} GPUs: CFG pair (RCCL all-gather of the network output per Euler step) x frame<->pixel sequence "
                 f"parallelism of degree {sp} (RCCL all-to-all around the temporal operators, all-reduce of the 5-D GroupNorm sums), "

@@ -258,13 +258,15 @@ class StreamingPipeline:
             key_frames = [video[s] for s in starts]                              # 1st frame of every window, enhanced first
             conds = codec.window_conditioning(images, 1, len(key_frames))         # the reference's order of random draws: image latents,
             lat = codec.encode_video(key_frames)                                 # video posterior, SDEdit noise (pipeline_i2vgen_xl.py:784-829)
-            images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng)))
+            images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng)))   # one window: nothing to shard
             video = video[:max_idx]
         else:
             starts, chunk_size, overlap_size = [0], len(video), 0
         conds = codec.window_conditioning(images, len(starts), chunk_size)
         lat = codec.encode_video(video)
-        return codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng))
+        # self.group (a torch.distributed group, default None): the blending windows of every DDIM step are sharded over its ranks
+        # (blending.blend_step_sharded: identical offsets on every rank, one all-gather of the window outputs per step)
+        return codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng, group=getattr(self, "group", None)))
 
     def interpolate_video(self, video, dest_num_frames, **kwargs):
         """inference_i2v.py:211-224.  vfi: an `ema_vfi.EMAVFI` (the native EMA-VFI) or any callable vfi(video, dest_num_frames)."""
@@ -274,7 +276,8 @@ class StreamingPipeline:
         from .ema_vfi import EMAVFI, vfi_process
         if isinstance(self.vfi, EMAVFI):
             import numpy as np
-            frames = vfi_process(list(video), self.vfi, dest_num_frames, device=self.vfi.device)
+            grp = getattr(self, "group", None)
+            frames = vfi_process(list(video), self.vfi, dest_num_frames, device=self.vfi.device, group=grp, sharded=grp is not None)
             return np.stack([np.asarray(f) for f in frames], axis=0)
         return self.vfi(video, dest_num_frames)
 

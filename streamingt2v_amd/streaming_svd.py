@@ -47,6 +47,7 @@ class StreamingSVD:
                 outs.append(self.first_stage_model.decode(zc, timesteps=len(zc), clamp=clamp))
             return torch.cat(outs, dim=0)
         import torch.distributed as dist
+        from . import parallel
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         out = None
         mine = {}
@@ -59,7 +60,7 @@ class StreamingSVD:
             part = out[n * n_samples:(n + 1) * n_samples]
             if n in mine:
                 part.copy_(mine[n])
-            dist.broadcast(part, src=dist.get_global_rank(group, n % world), group=group)
+            parallel.broadcast(part, src=dist.get_global_rank(group, n % world), group=group)
         return out
 
     @torch.no_grad()

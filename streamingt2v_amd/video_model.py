@@ -525,6 +525,17 @@ class _EncoderBase:
     def eval(self):
         return self
 
+    def reset_caches(self):
+        """Drop the per-chunk caches (context tensors, one-token cross-attention constants, the ControlNet's condition embedding): they hold
+        strong references to the last chunk's `context` / control frames (~50 MB) and are keyed on tensor identity + version -- call this
+        between videos, or after writing an input through .data / set_() (which the version counter does not see)."""
+        self._ctx_cache = None
+        if hasattr(self, "_cond_cache"):
+            self._cond_cache = None
+        for m in self._modules():
+            if isinstance(m, SpatialVideoTransformer):
+                m._a2c = None
+
     def _build_encoder(self, cfg):
         mc, emb = cfg.model_channels, cfg.model_channels * 4
         self.cfg, self.mc, self.emb_ch = cfg, mc, emb
@@ -593,9 +604,10 @@ class _EncoderBase:
         # one `context` tensor -> one (ctx, tctx) pair: the Euler steps of a chunk pass the same tensor object, and the transformer blocks key
         # their per-chunk cross-attention constants on the identity of what they receive here
         cc = getattr(self, "_ctx_cache", None)
-        if cc is None or cc[0] is not context or cc[1] != context._version or cc[2] != (T, id(sp), ops.ELEM):
+        ver = ops.tensor_version(context)
+        if cc is None or ver is None or cc[0] is not context or cc[1] != ver or cc[2] != (T, id(sp), ops.ELEM):
             ctx, tctx = self._contexts(context, T)
-            self._ctx_cache = cc = (context, context._version, (T, id(sp), ops.ELEM), ctx if sp is None else sp.take_frames(ctx, B, T), tctx, sp)
+            self._ctx_cache = cc = (context, ver, (T, id(sp), ops.ELEM), ctx if sp is None else sp.take_frames(ctx, B, T), tctx, sp)
         ctx, tctx = cc[3], cc[4]
         if sp is None:
             return emb_full, emb_full, ctx, tctx, timesteps.numel()
@@ -816,10 +828,11 @@ class ControlNet(_EncoderBase):
         distinct input tensor and reused across the Euler steps of a chunk (the reference recomputes it every
         step, controlnet.py:520; the values are identical)."""
         c = self._cond_cache
-        if c is None or c[0] is not controlnet_cond or c[1] != controlnet_cond._version:
+        ver = ops.tensor_version(controlnet_cond)
+        if c is None or ver is None or c[0] is not controlnet_cond or c[1] != ver:
             # the cache keeps the input tensor alive: identity (not address) decides, so a freed-and-reallocated buffer of the
             # next video can never alias a stale embedding
-            self._cond_cache = c = (controlnet_cond, controlnet_cond._version, self.controlnet_cond_embedding.forward(controlnet_cond)[0])
+            self._cond_cache = c = (controlnet_cond, ver, self.controlnet_cond_embedding.forward(controlnet_cond)[0])
         return c[2]
 
     def forward_tokens(self, x_tok, timesteps, controlnet_cond, context, y, T, H, W, sp=None):

@@ -45,8 +45,9 @@ class StreamingWrapper:
             # only CLIP token 0 (wrappers.py:39).  One derived tensor per `context` OBJECT: the networks recognise a chunk's constant context by
             # identity and compute its cross-attention constants once per chunk instead of once per Euler step (video_model._attn2_const)
             held = getattr(self, "_ctx_ctrl", None)
-            if held is None or held[0] is not context or held[1] != context._version or held[2] != (batch_size, T, Tc):
-                self._ctx_ctrl = held = (context, context._version, (batch_size, T, Tc), reduce_rows(context[:, :1], 1))
+            ver = ops.tensor_version(context)
+            if held is None or ver is None or held[0] is not context or held[1] != ver or held[2] != (batch_size, T, Tc):
+                self._ctx_ctrl = held = (context, ver, (batch_size, T, Tc), reduce_rows(context[:, :1], 1))
             ctx_ctrl = held[3]
             y_ctrl = reduce_rows(y, 1)
             # ... and the pixel-space control frames, repeated for both CFG halves (wrappers.py:45-48)
@@ -67,13 +68,21 @@ class StreamingWrapper:
         # collide once the tensor is freed and the caching allocator hands the same address to the next video's control frames.
         # With sequence parallelism the cached tensor holds this rank's share of the conditioning frames.
         held = getattr(self, "_cond_src", None)
-        if held is None or held[0] is not ctrl_frames or held[1] != ctrl_frames._version or held[2] != batch_size or held[3] is not self.sp:
+        ver = ops.tensor_version(ctrl_frames)
+        if held is None or ver is None or held[0] is not ctrl_frames or held[1] != ver or held[2] != batch_size or held[3] is not self.sp:
             cond = ctrl_frames.repeat(batch_size // ctrl_frames.shape[0], *([1] * (ctrl_frames.dim() - 1))).flatten(0, 1)
             if self.sp is not None:
                 cond = self.sp.take_frames(cond, batch_size, self.num_frame_conditioning)
-            self._cond_src = (ctrl_frames, ctrl_frames._version, batch_size, self.sp)
+            self._cond_src = (ctrl_frames, ver, batch_size, self.sp)
             self._cond_val = cond.float().contiguous()
         return self._cond_val
+
+    def reset_caches(self):
+        """Release the per-chunk caches of the wrapper and of both networks (see _EncoderBase.reset_caches): between videos."""
+        self._ctx_ctrl = self._cond_src = self._cond_val = None
+        for net in (self.diffusion_model, self.controlnet):
+            if net is not None and hasattr(net, "reset_caches"):
+                net.reset_caches()
 
     # ---- reference-shaped entry point ------------------------------------------------------------------------
     def forward(self, x, t, c, **kwargs):

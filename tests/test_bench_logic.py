@@ -63,3 +63,57 @@ def test_roofline_groups_the_gemm_instantiations_into_one_kernel_family():
     assert abs(r["share_of_traced_time"] - 18.0 / 33.0) < 1e-3
     assert r["traffic"]["signature"] == "m0_A" and r["traffic"]["algorithmic_bytes_per_launch"] == 1e9
     assert set(r["traced_kernels"]) == {"gemm_cfg20_mode0", "gemm_cfg21_mode1", "attn_spatial_d64", "gn_apply"}
+
+
+def test_stage1_stream_can_start_inside_a_video_so_that_warmup_ends_at_a_boundary():
+    """bench.run_stage1 starts the stream (-warmup) mod 6 chunks into a video on stand-in control frames: after the warm-up steps the timed
+    region begins with chunk 0 whatever --warmup is (round-2 advice: a timed window that starts mid-video inflates or deflates frames/s)."""
+    import bench
+    for warmup in (0, 1, 5, 6, 7):
+        m = _FakeModel()
+        start = (-warmup) % 6
+        s = bench.Stage1Stream(m, None, None, [None] * 6, start=start, prev_frames=torch.full((7, 3, 2, 2), -5.0) if start else None)
+        for _ in range(warmup):
+            s.step()
+        assert s.i % 6 == 0, warmup
+        if start:
+            assert m.calls[0] == ("ar", -5.0)                    # the first warm-up AR chunk ran on the stand-in frames
+        n0 = len(m.calls)
+        kept = [s.step() for _ in range(6)]
+        assert kept == [25, 18, 18, 18, 18, 3] and m.calls[n0][0] == "chunk0"
+
+
+def test_self_spawn_builds_a_single_node_launcher_command(monkeypatch):
+    """`python bench.py --gpus N` (how the driver's scaling run invokes it) re-executes itself under torch.distributed.run with N ranks on
+    127.0.0.1 and passes the exit code through (round-2 verdict: it used to die on an assert before a kernel launched)."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    try:
+        bench.self_spawn(4)
+        raise AssertionError("self_spawn must exit with the launcher's return code")
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_job_plan_is_validated_up_front():
+    """Shapes the CFG-pair x sequence-parallel plan cannot carry are refused before any model is built (round-2 advice), with the reason."""
+    from streamingt2v_amd.parallel import JobPlan
+    assert JobPlan.validate(2) is None and JobPlan.validate(4) is None and JobPlan.validate(8) is None
+    assert "even" in JobPlan.validate(3)
+    assert "conditioning frames" in JobPlan.validate(16)              # sp = 8 > 7 ControlNet frames
+    assert "divisible" in JobPlan.validate(10)                        # sp = 5 does not divide the 144 pixels of the lowest level
+    p = JobPlan(world=16, rank=3, mode="job")                         # no process group needed: the plan falls back before creating any
+    assert p.mode == "replica" and p.scaling == "weak" and p.n_videos == 16 and p.video_id == 3 and "fell back" in p.describe()

@@ -60,7 +60,7 @@ def world(request):
 
     yield dict(model=model, O=O, sd_u=sd_u, sd_c=sd_c, sd_d=sd_d, ocfg=ocfg, vcfg=vcfg, T=T, Tc=Tc, noises=noises, image=image,
                conditioner=conditioner, name=str(request.param)[6:], is16=request.param == torch.float16)
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
 
 
 def _l2(got, ref):

@@ -21,7 +21,7 @@ def full_unet():
     from streamingt2v_amd.params import init_by_name
     from streamingt2v_amd.video_model import UNetConfig, VideoUNet
     from streamingt2v_amd.wrappers import StreamingWrapper
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
     unet = VideoUNet(UNetConfig())
     unet.load_state_dict(init_by_name(unet.spec(), seed=33, device="cuda"), device="cuda")
     torch.cuda.empty_cache()
@@ -54,7 +54,7 @@ def test_full_size_forward_deterministic_and_cfg_halves_independent(full_unet):
 def test_full_size_gemm_tile_config_independence():
     from streamingt2v_amd import ops
     from streamingt2v_amd.video_model import pack_geglu
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
     M, K, N = 460800, 320, 2560
     g = torch.Generator(device="cuda"); g.manual_seed(6)
     a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
@@ -75,7 +75,7 @@ def test_full_size_gemm_tile_config_independence():
 
 def test_full_size_attention_properties():
     from streamingt2v_amd import ops
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
     frames, n, heads = 4, 9216, 5
     C = heads * 64
     g = torch.Generator(device="cuda"); g.manual_seed(7)
@@ -101,7 +101,7 @@ def test_full_size_enhancer_deterministic_and_cfg_halves_independent():
     from streamingt2v_amd import ops
     from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
     from streamingt2v_amd.params import init_by_name
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
     unet = I2VGenXLUNet(I2VConfig())
     unet.load_state_dict(init_by_name(unet.spec(), seed=5, device="cuda"), device="cuda")
     torch.cuda.empty_cache()
@@ -127,7 +127,7 @@ def test_full_size_vae_decode_deterministic():
     from streamingt2v_amd import ops
     from streamingt2v_amd.params import init_by_name
     from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VideoDecoder
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
     dec = VideoDecoder()
     dec.load_state_dict(init_by_name(dec.spec(), seed=35, device="cuda"), device="cuda")
     vae = AutoencodingEngineDecoder(dec)
@@ -152,7 +152,7 @@ def test_full_size_vfi_rotation_equivariance_and_determinism():
     from streamingt2v_amd import ops
     from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
     from streamingt2v_amd.params import init_by_name
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
     torch.set_grad_enabled(False)
     m = EMAVFI(VFIConfig())
     m.load_state_dict(init_by_name(m.spec(), seed=3), device="cuda")

@@ -98,5 +98,5 @@ def test_shipped_architecture_small_latent_vs_reference(dtype, golden_dir):
         k = 1.0 if f16 else 9.0          # bf16: one rounding is 8x coarser
         assert e_w <= 1.5e-3 * k and e_u <= 1.25e-3 * k and e_i2v <= 1.8e-3 * k and e_dec <= 1.3e-3 * k and e_enc <= 1.2e-3 * k
     finally:
-        ops.set_element_dtype(torch.bfloat16)
+        ops.set_element_dtype(None)
         torch.cuda.empty_cache()

@@ -26,7 +26,7 @@ def ops(request):
     TOLF = 1.0 if request.param == torch.bfloat16 else 0.25
     o.set_element_dtype(request.param)
     yield o
-    o.set_element_dtype(torch.bfloat16)
+    o.set_element_dtype(None)
 
 
 def rnd(*shape, scale=1.0, seed=0, dtype=None):

@@ -50,7 +50,7 @@ def elem(request):
     REL_L2 = 2e-2 if request.param == torch.bfloat16 else 4e-3
     ops.set_element_dtype(request.param)
     yield request.param
-    ops.set_element_dtype(torch.bfloat16)
+    ops.set_element_dtype(None)
 
 
 @pytest.fixture(scope="module")
