@@ -29,6 +29,12 @@ typedef uint16_t svd_bf16;       /* raw 16-bit element (bf16 or fp16 bits, see `
 /* element type of every 16-bit tensor of a call: bf16 (default, north_star) or fp16 (the reference's own autocast
  * precision, config.yaml:8).  Storage 16 bit, accumulation / statistics fp32 in both.  SVD_DTYPE_F32 only where stated. */
 enum { SVD_DTYPE_BF16 = 0, SVD_DTYPE_F16 = 1, SVD_DTYPE_F32 = 2 };
+/* OR-ed into the 16-bit `dtype` of the READERS of the fp32 residual stream (svd_groupnorm_stats / _sums / _apply, svd_layernorm,
+ * svd_add_rows): the input X (and svd_layernorm's Xsum / svd_add_rows' Y, which continue the stream) is fp32 with leading dimensions in
+ * fp32 elements; the normalised output Y -- a GEMM operand -- stays in the 16-bit type.  The stream option keeps the tensors the
+ * reference's residual additions run on (models/svd/sgm/modules/diffusionmodules/openaimodel.py:351-354, attention.py:567-593,
+ * video_attention.py:125-168) in fp32 between the kernels: only what a matrix core consumes is rounded to 16 bit. */
+enum { SVD_DTYPE_IN_F32 = 0x100 };
 
 enum {
     SVD_OK = 0,
@@ -93,6 +99,7 @@ typedef struct svd_gemm_args {
     uint64_t* dbg_cycles;                 /* optional (NULL in production): 8 x u64 phase cycle counters of block 0 / wave 0 */
     int32_t pad_mode;                     /* conv, stride 2: 0 = zero padding 1 on every side; 1 = F.pad (0,1,0,1) then padding 0
                                              (Downsample of the VAE encoder, sgm/modules/diffusionmodules/model.py:73-92) */
+    int32_t res_f32;                      /* 1: R and S are fp32 (the fp32 residual stream; ldr / lds in fp32 elements), 0: 16-bit `dtype` */
 } svd_gemm_args;
 
 int svd_gemm(const svd_gemm_args* args, svd_stream_t stream);
@@ -153,10 +160,10 @@ int svd_softmax_rows(const float* S, int64_t lds, svd_bf16* P, int64_t ldp, int6
  *   partial: workspace float, >= svd_groupnorm_partial_elems(...) elements.
  */
 int64_t svd_groupnorm_partial_elems(int32_t frames, int32_t channels);
-int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
+int svd_groupnorm_stats(const void* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
                         int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats,
                         int32_t dtype, svd_stream_t stream);
-int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
+int svd_groupnorm_apply(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
                         int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
                         const float* gamma, const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream);
 /* Sequence-parallel form of the 5-D statistics (time_stack GroupNorms models/diffusion/video_model.py:75-80 and the CAM merger's
@@ -164,7 +171,7 @@ int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy
  * are sharded over the ranks of a process group, every rank reduces ITS rows to sums[frames/frames_per_stat][groups][2] = (sum, sum of
  * squares) in double, the ranks add them (RCCL all-reduce of 2 x 32 x batch doubles), and svd_groupnorm_stats_from_sums forms
  * (mean, rstd) with the GLOBAL element count -- svd_groupnorm_apply then runs unchanged on the local rows. */
-int svd_groupnorm_sums(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels, int32_t groups,
+int svd_groupnorm_sums(const void* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels, int32_t groups,
                        int32_t frames_per_stat, float* partial, double* sums, int32_t dtype, svd_stream_t stream);
 int svd_groupnorm_stats_from_sums(const double* sums, int32_t nstat, int32_t groups, double count, float eps, float* stats,
                                   svd_stream_t stream);
@@ -174,9 +181,9 @@ int svd_groupnorm_stats_from_sums(const double* sums, int32_t nstat, int32_t gro
  * (ControlNetConditioningEmbedding per-pixel LN + SiLU, models/control/controlnet.py:108-114).
  * Replaces nn.LayerNorm of attention.py:528-530, video_attention.py:59,87,101-102.
  */
-int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
+int svd_layernorm(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
                   const float* gamma, const float* beta, float eps,
-                  const float* addvec, int32_t addvec_ld, int32_t rows_per_vec, svd_bf16* Xsum, int64_t ldxsum,
+                  const float* addvec, int32_t addvec_ld, int32_t rows_per_vec, void* Xsum, int64_t ldxsum,
                   int32_t silu, int32_t dtype, svd_stream_t stream);
 
 /* ---- layout / elementwise glue ---------------------------------------------------------------------------- */
@@ -191,8 +198,18 @@ int svd_tokens_to_nchw(const void* X, int32_t x_dtype, int64_t ldx, float* Y, in
 int svd_concat_channels(const svd_bf16* A, int64_t lda, int32_t ca, const svd_bf16* B, int64_t ldb, int32_t cb,
                         svd_bf16* Y, int64_t ldy, int64_t rows, svd_stream_t stream);
 /* Y = X + B (row-wise, same shape)  (Merger addition, controlnet.py:41-42) */
-int svd_add_rows(const svd_bf16* X, int64_t ldx, const svd_bf16* B, int64_t ldb, svd_bf16* Y, int64_t ldy,
+int svd_add_rows(const void* X, int64_t ldx, const svd_bf16* B, int64_t ldb, void* Y, int64_t ldy,
                  int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream);
+/* fp32 rows -> 16-bit rows (channels % 8 == 0): the 16-bit operand copy of an fp32 residual-stream tensor where the reference feeds the
+ * stream straight into a convolution / linear (Downsample.op, Upsample.conv, skip_connection, the torch.cat of the decoder half
+ * video_model.py:606-611 -- two calls into the two column ranges of Y --, the ControlNet features the CAM mergers project). */
+int svd_cast_rows_f32(const float* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels, int32_t dtype,
+                      svd_stream_t stream);
+/* Y[i_{p0}][i_{p1}][i_{p2}][i_{p3}][:] = X[i0][i1][i2][i3][:] over rows of row_bytes (multiple of 16) bytes: the frame <-> pixel repack
+ * around the sequence-parallel all-to-all (replaces the "(b t) ... <-> b ... t" rearranges of video_model.py:75-80 /
+ * video_attention.py:289-325 across ranks) in one pass. */
+int svd_permute_rows(const void* X, void* Y, int32_t n0, int32_t n1, int32_t n2, int32_t n3, int32_t p0, int32_t p1, int32_t p2,
+                     int32_t p3, int64_t row_bytes, svd_stream_t stream);
 /* fp32 -> 16-bit cast, optionally through SiLU (emb_layers' leading SiLU, openaimodel.py:284-290) */
 int svd_cast_f32(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, int32_t dtype, svd_stream_t stream);
 /* sinusoidal embedding [cos | sin], freqs = exp(-ln(max_period) * i / half)  (util.py:207-231) -> bf16 [n][dim] */

@@ -73,6 +73,59 @@ __global__ void add_rows_kernel(const svd_bf16* __restrict__ X, int64_t ldx, con
     }
 }
 
+// fp32 residual stream: Y(fp32) = X(fp32) + B(16 bit)
+template <class E>
+__global__ void add_rows_f32_kernel(const float* __restrict__ X, int64_t ldx, const svd_bf16* __restrict__ B, int64_t ldb,
+                                    float* __restrict__ Y, int64_t ldy, int64_t rows, int c) {
+    const int oct = c >> 3;
+    const int64_t total = rows * oct;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / oct;
+        const int o = (int)(i - r * oct);
+        const float* xp = X + r * ldx + o * 8;
+        const float4 a0 = *(const float4*)xp, a1 = *(const float4*)(xp + 4);
+        const uint4 b = *(const uint4*)(B + r * ldb + o * 8);
+        float* yp = Y + r * ldy + o * 8;
+        *(float4*)yp = make_float4(a0.x + E::lo(b.x), a0.y + E::hi(b.x), a0.z + E::lo(b.y), a0.w + E::hi(b.y));
+        *(float4*)(yp + 4) = make_float4(a1.x + E::lo(b.z), a1.y + E::hi(b.z), a1.z + E::lo(b.w), a1.w + E::hi(b.w));
+    }
+}
+
+// fp32 rows -> 16-bit rows, 8 channels per thread (the 16-bit operand copy of an fp32 residual-stream tensor: Downsample / Upsample / skip
+// convolution inputs, the two halves of the decoder's channel concatenation, the ControlNet features the CAM mergers project)
+template <class E>
+__global__ void cast_rows_f32_kernel(const float* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int64_t rows, int c) {
+    const int oct = c >> 3;
+    const int64_t total = rows * oct;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / oct;
+        const int o = (int)(i - r * oct);
+        const float* xp = X + r * ldx + o * 8;
+        const float4 a0 = *(const float4*)xp, a1 = *(const float4*)(xp + 4);
+        uint4 w;
+        w.x = E::pack(a0.x, a0.y); w.y = E::pack(a0.z, a0.w); w.z = E::pack(a1.x, a1.y); w.w = E::pack(a1.z, a1.w);
+        *(uint4*)(Y + r * ldy + o * 8) = w;
+    }
+}
+
+// Row permutation of a 4-D array of rows: Y[i_{p0}][i_{p1}][i_{p2}][i_{p3}][:] = X[i0][i1][i2][i3][:], rows of `vec` 16-byte vectors.
+// The frame <-> pixel repack of the sequence-parallel all-to-all (parallel.SeqParallel.to_pixels / to_frames) in ONE pass.
+__global__ void permute_rows_kernel(const uint4* __restrict__ X, uint4* __restrict__ Y, int n0, int n1, int n2, int n3,
+                                    int64_t s0, int64_t s1, int64_t s2, int64_t s3, int vec) {
+    // s_k: stride (in rows) of SOURCE dimension k inside the DESTINATION
+    const int64_t total = (int64_t)n0 * n1 * n2 * n3 * vec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / vec;
+        const int v = (int)(i - row * vec);
+        int64_t q = row;
+        const int i3 = (int)(q % n3); q /= n3;
+        const int i2 = (int)(q % n2); q /= n2;
+        const int i1 = (int)(q % n1); q /= n1;
+        const int i0 = (int)q;
+        Y[(i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3) * vec + v] = X[i];
+    }
+}
+
 template <class E>
 __global__ void cast_f32_kernel(const float* __restrict__ X, svd_bf16* __restrict__ Y, int64_t n, int apply) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -226,13 +279,53 @@ extern "C" int svd_concat_channels(const svd_bf16* A, int64_t lda, int32_t ca, c
     return SVD_OK;
 }
 
-extern "C" int svd_add_rows(const svd_bf16* X, int64_t ldx, const svd_bf16* B, int64_t ldb, svd_bf16* Y, int64_t ldy,
+extern "C" int svd_add_rows(const void* X, int64_t ldx, const svd_bf16* B, int64_t ldb, void* Y, int64_t ldy,
                             int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream) {
     if (!X || !B || !Y || channels <= 0 || channels % 8 || ldx % 8 || ldb % 8 || ldy % 8 || rows <= 0) return SVD_EINVAL;
     if (((uintptr_t)X | (uintptr_t)B | (uintptr_t)Y) & 15) return SVD_EINVAL;
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_rows_kernel<E>, dim3(grid_for(rows * (channels / 8))), dim3(256), 0,
-                                                 (hipStream_t)stream, X, ldx, B, ldb, Y, ldy, rows, channels));
+    if (dtype & SVD_DTYPE_IN_F32) {      // fp32 residual stream: X and Y fp32, B 16 bit
+        SVD_DISPATCH_DTYPE(dtype & 0xff, hipLaunchKernelGGL(add_rows_f32_kernel<E>, dim3(grid_for(rows * (channels / 8))), dim3(256), 0,
+                                                            (hipStream_t)stream, (const float*)X, ldx, B, ldb, (float*)Y, ldy, rows, channels));
+    } else {
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_rows_kernel<E>, dim3(grid_for(rows * (channels / 8))), dim3(256), 0,
+                                                     (hipStream_t)stream, (const svd_bf16*)X, ldx, B, ldb, (svd_bf16*)Y, ldy, rows, channels));
+    }
     SVD_CHECK_LAUNCH("add_rows");
+    return SVD_OK;
+}
+
+extern "C" int svd_cast_rows_f32(const float* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels, int32_t dtype,
+                                 svd_stream_t stream) {
+    if (!X || !Y || channels <= 0 || channels % 8 || ldx % 4 || ldy % 8 || rows <= 0) return SVD_EINVAL;
+    if (((uintptr_t)X | (uintptr_t)Y) & 15) return SVD_EINVAL;
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(cast_rows_f32_kernel<E>, dim3(grid_for(rows * (channels / 8))), dim3(256), 0,
+                                                 (hipStream_t)stream, X, ldx, Y, ldy, rows, channels));
+    SVD_CHECK_LAUNCH("cast_rows_f32");
+    return SVD_OK;
+}
+
+extern "C" int svd_permute_rows(const void* X, void* Y, int32_t n0, int32_t n1, int32_t n2, int32_t n3, int32_t p0, int32_t p1, int32_t p2,
+                                int32_t p3, int64_t row_bytes, svd_stream_t stream) {
+    if (!X || !Y || n0 <= 0 || n1 <= 0 || n2 <= 0 || n3 <= 0 || row_bytes <= 0 || row_bytes % 16) return SVD_EINVAL;
+    if (((uintptr_t)X | (uintptr_t)Y) & 15) return SVD_EINVAL;
+    const int perm[4] = {p0, p1, p2, p3};
+    const int64_t n[4] = {n0, n1, n2, n3};
+    int seen = 0;
+    for (int k = 0; k < 4; ++k) { if (perm[k] < 0 || perm[k] > 3) return SVD_EINVAL; seen |= 1 << perm[k]; }
+    if (seen != 15) return SVD_EINVAL;
+    // destination dims are n[perm[0..3]]; stride of source dim d inside the destination = product of the destination dims after its position
+    int64_t sd[4];
+    for (int d = 0; d < 4; ++d) {
+        int pos = 0;
+        for (int k = 0; k < 4; ++k) if (perm[k] == d) pos = k;
+        int64_t st = 1;
+        for (int k = pos + 1; k < 4; ++k) st *= n[perm[k]];
+        sd[d] = st;
+    }
+    const int vec = (int)(row_bytes / 16);
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(grid_for(n[0] * n[1] * n[2] * n[3] * vec)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)X, (uint4*)Y, n0, n1, n2, n3, sd[0], sd[1], sd[2], sd[3], vec);
+    SVD_CHECK_LAUNCH("permute_rows");
     return SVD_OK;
 }
 

@@ -5,6 +5,23 @@ namespace {
 
 constexpr int GN_MAXCHUNK = 256;
 
+// 8 consecutive channels of a row as fp32.  IN32 = the fp32 residual stream (dtype | SVD_DTYPE_IN_F32): the norms are the stream's readers,
+// their OUTPUT (a GEMM operand) stays 16 bit.
+template <class E, bool IN32>
+__device__ __forceinline__ void load8(const void* row, int c, float (&v)[8]) {
+    if constexpr (IN32) {
+        const float4 a = *(const float4*)((const float*)row + c), b = *(const float4*)((const float*)row + c + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const uint4 u = *(const uint4*)((const svd_bf16*)row + c);
+        v[0] = E::lo(u.x); v[1] = E::hi(u.x); v[2] = E::lo(u.y); v[3] = E::hi(u.y);
+        v[4] = E::lo(u.z); v[5] = E::hi(u.z); v[6] = E::lo(u.w); v[7] = E::hi(u.w);
+    }
+}
+template <bool IN32> __device__ __forceinline__ const void* row_ptr(const void* base, int64_t row, int64_t ld) {
+    return IN32 ? (const void*)((const float*)base + row * ld) : (const void*)((const svd_bf16*)base + row * ld);
+}
+
 __host__ __device__ inline int gn_nchunk(int frames, int pix) {
     // chunks of ~256 rows, a function of the frame size ONLY: the partial-sum grouping (and so every rounding of the statistics)
     // is then independent of how many frames are batched -- forward(batch 2) == concat(forward(half), forward(half)) bit for
@@ -18,8 +35,8 @@ __host__ __device__ inline int gn_nchunk(int frames, int pix) {
 
 // blockDim = octets * R ; thread -> fixed channel octet (8 channels), rows strided by R.
 // partial[f][chunk][g][2] = (sum, sumsq) over the chunk's pixels of group g.
-template <class E>
-__global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t ldx, int pix, int channels, int groups,
+template <class E, bool IN32>
+__global__ void gn_stats_partial_kernel(const void* __restrict__ X, int64_t ldx, int pix, int channels, int groups,
                                         int nchunk, float* __restrict__ partial) {
     extern __shared__ float sch[];   // [R][channels][2]: one slot per (row group, channel) -- summed in a FIXED order below
     const int octets = channels >> 3;
@@ -33,21 +50,21 @@ __global__ void gn_stats_partial_kernel(const svd_bf16* __restrict__ X, int64_t 
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
     if (rr < R) {
-        const svd_bf16* base = X + ((int64_t)f * pix) * ldx + o * 8;
-        auto acc8 = [&](const uint4 u) {
-            const float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y), E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
+        const void* base = row_ptr<IN32>(X, (int64_t)f * pix, ldx);
+        auto acc8 = [&](const float (&v)[8]) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { s[i] += v[i]; ss[i] += v[i] * v[i]; }
         };
         int r = r0 + rr;
-        for (; r + 3 * R < r1; r += 4 * R) {          // 4 independent 16-byte loads in flight per thread (HBM-latency bound otherwise)
-            const uint4 u0 = *(const uint4*)(base + (int64_t)r * ldx);
-            const uint4 u1 = *(const uint4*)(base + (int64_t)(r + R) * ldx);
-            const uint4 u2 = *(const uint4*)(base + (int64_t)(r + 2 * R) * ldx);
-            const uint4 u3 = *(const uint4*)(base + (int64_t)(r + 3 * R) * ldx);
+        for (; r + 3 * R < r1; r += 4 * R) {          // 4 independent row loads in flight per thread (HBM-latency bound otherwise)
+            float u0[8], u1[8], u2[8], u3[8];
+            load8<E, IN32>(row_ptr<IN32>(base, r, ldx), o * 8, u0);
+            load8<E, IN32>(row_ptr<IN32>(base, r + R, ldx), o * 8, u1);
+            load8<E, IN32>(row_ptr<IN32>(base, r + 2 * R, ldx), o * 8, u2);
+            load8<E, IN32>(row_ptr<IN32>(base, r + 3 * R, ldx), o * 8, u3);
             acc8(u0); acc8(u1); acc8(u2); acc8(u3);
         }
-        for (; r < r1; r += R) acc8(*(const uint4*)(base + (int64_t)r * ldx));
+        for (; r < r1; r += R) { float u[8]; load8<E, IN32>(row_ptr<IN32>(base, r, ldx), o * 8, u); acc8(u); }
         float* dst = sch + ((int64_t)rr * channels + o * 8) * 2;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { dst[2 * i] = s[i]; dst[2 * i + 1] = ss[i]; }
@@ -121,8 +138,8 @@ __global__ void gn_stats_from_sums_kernel(const double* __restrict__ sums, int n
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-template <class E>
-__global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int pix,
+template <class E, bool IN32>
+__global__ void gn_apply_kernel(const void* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int pix,
                                 int channels, int groups, int frames_per_stat, int nchunk, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int silu) {
     const int octets = channels >> 3;
@@ -144,10 +161,9 @@ __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd
         const float ga = gamma[c] * rstd;
         ca[i] = ga; cb[i] = beta[c] - mean * ga;
     }
-    const svd_bf16* xb = X + ((int64_t)f * pix) * ldx + o * 8;
+    const void* xb = row_ptr<IN32>(X, (int64_t)f * pix, ldx);
     svd_bf16* yb = Y + ((int64_t)f * pix) * ldy + o * 8;
-    auto one = [&](const uint4 u, int r) {
-        float v[8] = {E::lo(u.x), E::hi(u.x), E::lo(u.y), E::hi(u.y), E::lo(u.z), E::hi(u.z), E::lo(u.w), E::hi(u.w)};
+    auto one = [&](float (&v)[8], int r) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             v[i] = v[i] * ca[i] + cb[i];
@@ -160,23 +176,24 @@ __global__ void gn_apply_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd
     };
     int r = r0 + rr;
     for (; r + 3 * R < r1; r += 4 * R) {              // 4 independent loads in flight per thread
-        const uint4 u0 = *(const uint4*)(xb + (int64_t)r * ldx);
-        const uint4 u1 = *(const uint4*)(xb + (int64_t)(r + R) * ldx);
-        const uint4 u2 = *(const uint4*)(xb + (int64_t)(r + 2 * R) * ldx);
-        const uint4 u3 = *(const uint4*)(xb + (int64_t)(r + 3 * R) * ldx);
+        float u0[8], u1[8], u2[8], u3[8];
+        load8<E, IN32>(row_ptr<IN32>(xb, r, ldx), o * 8, u0);
+        load8<E, IN32>(row_ptr<IN32>(xb, r + R, ldx), o * 8, u1);
+        load8<E, IN32>(row_ptr<IN32>(xb, r + 2 * R, ldx), o * 8, u2);
+        load8<E, IN32>(row_ptr<IN32>(xb, r + 3 * R, ldx), o * 8, u3);
         one(u0, r); one(u1, r + R); one(u2, r + 2 * R); one(u3, r + 3 * R);
     }
-    for (; r < r1; r += R) one(*(const uint4*)(xb + (int64_t)r * ldx), r);
+    for (; r < r1; r += R) { float u[8]; load8<E, IN32>(row_ptr<IN32>(xb, r, ldx), o * 8, u); one(u, r); }
 }
 
 // LayerNorm: one wave per token row, NR rows per wave in flight (the kernel is latency-bound with one 16-byte load per lane
 // per row: 3.6 TB/s measured); up to MAXV 16-byte vectors per lane (C <= 64*8*MAXV).
-template <int MAXV, class E>
-__global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y,
+template <int MAXV, class E, bool IN32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y,
                                                         int64_t ldy, int64_t rows, int channels, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         const float* __restrict__ addvec, int addvec_ld, int rows_per_vec,
-                                                        svd_bf16* __restrict__ Xsum, int64_t ldxsum, int silu) {
+                                                        void* __restrict__ Xsum, int64_t ldxsum, int silu) {
     constexpr int NR = (MAXV <= 2) ? 2 : 1;
     const int lane = threadIdx.x & 63;
     const int octets = channels >> 3;
@@ -189,24 +206,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const svd_bf16* __restri
         for (int j = 0; j < NR; ++j) {
             sum[j] = 0.f;
             int64_t row = row0 + j; if (row > rows - 1) row = rows - 1;            // tail: recompute the last row, store masked below
-            const svd_bf16* xr = X + row * ldx;
+            const void* xr = row_ptr<IN32>(X, row, ldx);
             const float* av = addvec ? addvec + (row / rows_per_vec) * addvec_ld : nullptr;
 #pragma unroll
             for (int k = 0; k < MAXV; ++k) {
                 const int o = lane + 64 * k;
                 if (o < octets) {
-                    const uint4 u = *(const uint4*)(xr + o * 8);
-                    v[j][k][0] = E::lo(u.x); v[j][k][1] = E::hi(u.x); v[j][k][2] = E::lo(u.y); v[j][k][3] = E::hi(u.y);
-                    v[j][k][4] = E::lo(u.z); v[j][k][5] = E::hi(u.z); v[j][k][6] = E::lo(u.w); v[j][k][7] = E::hi(u.w);
+                    load8<E, IN32>(xr, o * 8, v[j][k]);
                     if (av) {
                         const float4 a0 = *(const float4*)(av + o * 8), a1 = *(const float4*)(av + o * 8 + 4);
                         v[j][k][0] += a0.x; v[j][k][1] += a0.y; v[j][k][2] += a0.z; v[j][k][3] += a0.w;
                         v[j][k][4] += a1.x; v[j][k][5] += a1.y; v[j][k][6] += a1.z; v[j][k][7] += a1.w;
                         if (Xsum && row0 + j < rows) {
-                            uint4 w;
-                            w.x = E::pack(v[j][k][0], v[j][k][1]); w.y = E::pack(v[j][k][2], v[j][k][3]);
-                            w.z = E::pack(v[j][k][4], v[j][k][5]); w.w = E::pack(v[j][k][6], v[j][k][7]);
-                            *(uint4*)(Xsum + row * ldxsum + o * 8) = w;
+                            if constexpr (IN32) {          // the sum continues the fp32 residual stream
+                                float* xs = (float*)Xsum + row * ldxsum + o * 8;
+                                *(float4*)xs = make_float4(v[j][k][0], v[j][k][1], v[j][k][2], v[j][k][3]);
+                                *(float4*)(xs + 4) = make_float4(v[j][k][4], v[j][k][5], v[j][k][6], v[j][k][7]);
+                            } else {
+                                uint4 w;
+                                w.x = E::pack(v[j][k][0], v[j][k][1]); w.y = E::pack(v[j][k][2], v[j][k][3]);
+                                w.z = E::pack(v[j][k][4], v[j][k][5]); w.w = E::pack(v[j][k][6], v[j][k][7]);
+                                *(uint4*)((svd_bf16*)Xsum + row * ldxsum + o * 8) = w;
+                            }
                         }
                     }
 #pragma unroll
@@ -270,7 +291,14 @@ extern "C" int64_t svd_groupnorm_partial_elems(int32_t frames, int32_t channels)
     return (int64_t)frames * GN_MAXCHUNK * 64;
 }
 
-extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
+#define SVD_DISPATCH_IN(dtype, ...)                                                              \
+    do {                                                                                         \
+        const int base_dt__ = (dtype) & 0xff;                                                    \
+        if ((dtype) & SVD_DTYPE_IN_F32) { constexpr bool IN32 = true; SVD_DISPATCH_DTYPE(base_dt__, __VA_ARGS__); } \
+        else { constexpr bool IN32 = false; SVD_DISPATCH_DTYPE(base_dt__, __VA_ARGS__); }        \
+    } while (0)
+
+extern "C" int svd_groupnorm_stats(const void* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels,
                                    int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats,
                                    int32_t dtype, svd_stream_t stream) {
     if (!X || !partial || !stats || frames <= 0 || pix <= 0 || channels <= 0) return SVD_EINVAL;
@@ -279,8 +307,8 @@ extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frame
     if ((uintptr_t)X & 15) return SVD_EINVAL;
     const int nchunk = gn_nchunk(frames, pix);
     const int bs = gn_block(channels);
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_stats_partial_kernel<E>, dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
-                                                 (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_stats_partial_kernel<E, IN32>), dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
+                                              (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
     SVD_CHECK_LAUNCH("gn_stats_partial");
     const int nstat = frames / frames_per_stat;
     const float count = (float)frames_per_stat * (float)pix * (float)(channels / groups);
@@ -290,7 +318,7 @@ extern "C" int svd_groupnorm_stats(const svd_bf16* X, int64_t ldx, int32_t frame
     return SVD_OK;
 }
 
-extern "C" int svd_groupnorm_sums(const svd_bf16* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels, int32_t groups,
+extern "C" int svd_groupnorm_sums(const void* X, int64_t ldx, int32_t frames, int32_t pix, int32_t channels, int32_t groups,
                                   int32_t frames_per_stat, float* partial, double* sums, int32_t dtype, svd_stream_t stream) {
     if (!X || !partial || !sums || frames <= 0 || pix <= 0 || channels <= 0) return SVD_EINVAL;
     if (groups <= 0 || groups > 32 || channels % groups || channels % 8 || ldx % 8 || channels > 8192) return SVD_EINVAL;
@@ -298,8 +326,8 @@ extern "C" int svd_groupnorm_sums(const svd_bf16* X, int64_t ldx, int32_t frames
     if (((uintptr_t)X & 15) || ((uintptr_t)sums & 7)) return SVD_EINVAL;
     const int nchunk = gn_nchunk(frames, pix);
     const int bs = gn_block(channels);
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_stats_partial_kernel<E>, dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
-                                                 (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_stats_partial_kernel<E, IN32>), dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
+                                              (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
     SVD_CHECK_LAUNCH("gn_stats_partial");
     hipLaunchKernelGGL(gn_sums_kernel, dim3((frames / frames_per_stat) * groups), dim3(64), 0, (hipStream_t)stream, partial, groups, frames_per_stat,
                        nchunk, sums);
@@ -316,7 +344,7 @@ extern "C" int svd_groupnorm_stats_from_sums(const double* sums, int32_t nstat, 
     return SVD_OK;
 }
 
-extern "C" int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
+extern "C" int svd_groupnorm_apply(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
                                    int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
                                    const float* gamma, const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream) {
     if (!X || !Y || !stats || !gamma || !beta || frames <= 0 || pix <= 0) return SVD_EINVAL;
@@ -325,15 +353,15 @@ extern "C" int svd_groupnorm_apply(const svd_bf16* X, int64_t ldx, svd_bf16* Y, 
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return SVD_EINVAL;
     const int nchunk = gn_nchunk(frames, pix);
     const int bs = gn_block(channels);
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gn_apply_kernel<E>, dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy,
-                                                 pix, channels, groups, frames_per_stat, nchunk, stats, gamma, beta, silu));
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_apply_kernel<E, IN32>), dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy,
+                                              pix, channels, groups, frames_per_stat, nchunk, stats, gamma, beta, silu));
     SVD_CHECK_LAUNCH("gn_apply");
     return SVD_OK;
 }
 
-extern "C" int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
+extern "C" int svd_layernorm(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels,
                              const float* gamma, const float* beta, float eps, const float* addvec, int32_t addvec_ld,
-                             int32_t rows_per_vec, svd_bf16* Xsum, int64_t ldxsum, int32_t silu, int32_t dtype, svd_stream_t stream) {
+                             int32_t rows_per_vec, void* Xsum, int64_t ldxsum, int32_t silu, int32_t dtype, svd_stream_t stream) {
     if (!X || !Y || !gamma || !beta || rows <= 0 || channels <= 0 || channels % 8 || ldx % 8 || ldy % 8) return SVD_EINVAL;
     if (channels > 64 * 8 * 4) return SVD_EINVAL;
     if (addvec && (rows_per_vec <= 0 || addvec_ld % 4)) return SVD_EINVAL;
@@ -343,9 +371,9 @@ extern "C" int svd_layernorm(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int64_
     if (blocks > 256 * 32) blocks = 256 * 32;
     const int octets = channels / 8;
 #define LN_LAUNCH(MV)                                                                                                        \
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_kernel<MV, E>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
-                                                 X, ldx, Y, ldy, rows, channels, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,    \
-                                                 Xsum, ldxsum, silu))
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((layernorm_kernel<MV, E, IN32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
+                                              X, ldx, Y, ldy, rows, channels, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,    \
+                                              Xsum, ldxsum, silu))
     if (octets <= 64) LN_LAUNCH(1);
     else if (octets <= 128) LN_LAUNCH(2);
     else if (octets <= 192) LN_LAUNCH(3);

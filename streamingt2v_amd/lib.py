@@ -30,14 +30,14 @@ def _lib_file():
 
 LIB_PATH = os.path.join(_HERE, _lib_file())
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
     "svd_abi_version", "svd_last_error", "svd_gemm", "svd_gemm_num_configs", "svd_gemm_config_info", "svd_gemm_pick_config", "svd_gemm_config_valid",
     "svd_attn_spatial_d64", "svd_attn_temporal_d64", "svd_softmax_rows",
     "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_groupnorm_sums", "svd_groupnorm_stats_from_sums", "svd_layernorm",
-    "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32",
+    "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32", "svd_cast_rows_f32", "svd_permute_rows",
     "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
     "svd_attn_cross_d64", "svd_adaptive_avgpool_tokens", "svd_i2v_image_temporal_encoder", "svd_ddim_cfg_step", "svd_frames_to_uint8", "svd_gelu_rows",
     "svd_prelu_rows", "svd_dwconv3x3_gelu", "svd_window_attn_7x7", "svd_warp_bilinear", "svd_resize_bilinear_f32", "svd_vfi_merge", "svd_vfi_tta_average",
@@ -48,6 +48,7 @@ OUT_BF16, OUT_F32, OUT_BF16_T = 0, 1, 2
 EPI_GEGLU = 1
 EPI_SILU = 2
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
+DTYPE_IN_F32 = 0x100      # OR-ed into a 16-bit dtype: the input of a norm / add_rows is the fp32 residual stream
 
 
 class GemmArgs(C.Structure):
@@ -76,6 +77,7 @@ class GemmArgs(C.Structure):
         ("dtype", C.c_int32),
         ("dbg_cycles", C.c_void_p),
         ("pad_mode", C.c_int32),
+        ("res_f32", C.c_int32),
     ]
 
 
@@ -114,6 +116,8 @@ def _load():
     lib.svd_concat_channels.argtypes = [vp, i64, i32, vp, i64, i32, vp, i64, i64, vp]
     lib.svd_add_rows.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
     lib.svd_cast_f32.argtypes = [vp, vp, i64, i32, i32, vp]
+    lib.svd_cast_rows_f32.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp]
+    lib.svd_permute_rows.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp]
     lib.svd_timestep_embedding.argtypes = [vp, i32, i32, f32, vp, i32, vp]
     lib.svd_edm_euler_step.argtypes = [vp, vp, i64, vp, i32, i32, i32, f32, f32, vp]
     lib.svd_ae_time_mix3.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, vp]

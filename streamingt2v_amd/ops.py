@@ -24,6 +24,19 @@ DEFAULT_ELEM = torch.float16
 ELEM = DEFAULT_ELEM
 
 
+# fp32 RESIDUAL STREAM (round 3): the tensors the reference's residual additions run on (ResBlock h + skip, transformer x + attn(x),
+# x + ff(x), the alpha-blends; openaimodel.py:351-354, attention.py:567-593, video_attention.py:125-168) stay fp32 BETWEEN the kernels of
+# the VideoUNet / ControlNet: GEMM epilogues read the residual and write the sum in fp32 (svd_gemm_args.res_f32 / SVD_OUT_F32), the norms
+# read fp32 (SVD_DTYPE_IN_F32) and write the 16-bit GEMM operand.  Only what a matrix core consumes is rounded to 16 bit -- the
+# "operand-only floor" of oracle/measure_precision_floor.py.  Cost: the stream's bytes double (norm reads, residual reads, output writes).
+STREAM_F32 = True
+
+
+def set_stream_f32(on=True):
+    global STREAM_F32
+    STREAM_F32 = bool(on)
+
+
 def set_element_dtype(dt=None):
     """Select the 16-bit element type of everything created from here on (None: back to DEFAULT_ELEM).  Call it BEFORE load_state_dict:
     packed weights keep the type they were packed in."""
@@ -35,6 +48,16 @@ def set_element_dtype(dt=None):
 
 def _dt(t):
     return _DT[t.dtype]
+
+
+def _dt_in(x):
+    """dtype argument of a norm / add_rows whose input may be the fp32 residual stream: 16-bit element type (| IN_F32)."""
+    return (_DT[ELEM] | _l.DTYPE_IN_F32) if x.dtype == torch.float32 else _DT[x.dtype]
+
+
+def _odt(x):
+    """16-bit type of the output a norm derives from x."""
+    return ELEM if x.dtype == torch.float32 else x.dtype
 
 
 def tensor_version(t):
@@ -67,7 +90,7 @@ def _load_tile_table():
 
 def gemm_signature(a):
     # the tile choice does not depend on the element type (bf16 and fp16 MFMA have the same shape and rate)
-    return f"m{a.a_mode}_M{a.M}_N{a.N}_K{a.K}_s{a.stride}_u{a.ups}_e{a.epi_flags}_o{a.out_mode}"
+    return f"m{a.a_mode}_M{a.M}_N{a.N}_K{a.K}_s{a.stride}_u{a.ups}_e{a.epi_flags}_o{a.out_mode}"      # (res_f32 rides with o1: same tile ranking)
 
 
 _tile_table = _load_tile_table()
@@ -131,13 +154,18 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
     if rowvec is not None:
         assert rowvec.dtype == torch.float32 and rowvec.stride(-1) == 1
         args.rowvec, args.rowvec_ld, args.rows_per_vec = rowvec.data_ptr(), rowvec.stride(0), rows_per_vec
+    r32 = None
     if residual is not None:
-        assert residual.dtype == edt
+        assert residual.dtype in (edt, torch.float32) and residual.stride(1) == 1
+        r32 = residual.dtype == torch.float32
         args.R, args.ldr = residual.data_ptr(), residual.stride(0)
     if blend is not None:
         alpha, S = blend
-        assert S.dtype == edt
+        assert S.dtype in (edt, torch.float32) and S.stride(1) == 1
+        assert r32 is None or r32 == (S.dtype == torch.float32), "residual and blend partner must both be 16-bit or both fp32 (the stream)"
+        r32 = S.dtype == torch.float32
         args.S, args.lds, args.alpha = S.data_ptr(), S.stride(0), float(alpha)
+    args.res_f32 = int(bool(r32))
     nout = N // 2 if geglu else N
     if n_out is not None:
         nout = n_out
@@ -174,7 +202,7 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
         src_rows = a.shape[0] if conv is None else conv["frames"] * conv["hin"] * conv["win"]
         src_cols = K if (conv is None and temporal is None) else args.cin
         nbytes = (src_rows * src_cols + N * K) * esz + M * nout * (4 if out.dtype == torch.float32 else esz)
-        nbytes += M * nout * esz * ((residual is not None) + (blend is not None))
+        nbytes += M * nout * (4 if r32 else esz) * ((residual is not None) + (blend is not None))
         with trace.launch(f"gemm_cfg{cfg}_mode{args.a_mode}", flops=2.0 * M * N * K, sig=gemm_signature(args), nbytes=float(nbytes)):
             check(_lib.svd_gemm(C.byref(args), _stream()), f"svd_gemm(M={M},N={N},K={K},mode={args.a_mode})")
         return out
@@ -228,11 +256,11 @@ def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False
     assert frames % frames_per_stat == 0
     partial, stats = _gn_workspace(x.device, frames, Cc, frames // frames_per_stat, groups)
     check(_lib.svd_groupnorm_stats(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, float(eps), _p(partial),
-                                   _p(stats), _dt(x), _stream()), "svd_groupnorm_stats")
+                                   _p(stats), _dt_in(x), _stream()), "svd_groupnorm_stats")
     if out is None:
-        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+        out = torch.empty((rows, Cc), dtype=_odt(x), device=x.device)
     check(_lib.svd_groupnorm_apply(_p(x), ld, _p(out), out.stride(0), frames, pix, Cc, groups, frames_per_stat,
-                                   _p(stats), _p(gamma), _p(beta), int(silu), _dt(x), _stream()), "svd_groupnorm_apply")
+                                   _p(stats), _p(gamma), _p(beta), int(silu), _dt_in(x), _stream()), "svd_groupnorm_apply")
     return out
 
 
@@ -244,7 +272,7 @@ def groupnorm_sums(x, frames, pix, frames_per_stat, groups=32):
     assert rows == frames * pix and frames % frames_per_stat == 0
     partial, _ = _gn_workspace(x.device, frames, Cc, frames // frames_per_stat, groups)
     sums = torch.empty((frames // frames_per_stat, groups, 2), dtype=torch.float64, device=x.device)
-    check(_lib.svd_groupnorm_sums(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, _p(partial), _p(sums), _dt(x), _stream()),
+    check(_lib.svd_groupnorm_sums(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, _p(partial), _p(sums), _dt_in(x), _stream()),
           "svd_groupnorm_sums")
     return sums
 
@@ -259,9 +287,9 @@ def groupnorm_apply_sums(x, frames, pix, gamma, beta, eps, sums, count, *, frame
     check(_lib.svd_groupnorm_stats_from_sums(_p(sums), nstat, groups, float(count), float(eps), _p(stats), _stream()),
           "svd_groupnorm_stats_from_sums")
     if out is None:
-        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+        out = torch.empty((rows, Cc), dtype=_odt(x), device=x.device)
     check(_lib.svd_groupnorm_apply(_p(x), ld, _p(out), out.stride(0), frames, pix, Cc, groups, frames_per_stat,
-                                   _p(stats), _p(gamma), _p(beta), int(silu), _dt(x), _stream()), "svd_groupnorm_apply")
+                                   _p(stats), _p(gamma), _p(beta), int(silu), _dt_in(x), _stream()), "svd_groupnorm_apply")
     return out
 
 
@@ -269,11 +297,11 @@ def layernorm(x, gamma, beta, *, eps=1e-5, addvec=None, rows_per_vec=0, want_sum
     rows, ld = _rows_ld(x)
     Cc = x.shape[1]
     if out is None:
-        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
-    xsum = torch.empty((rows, Cc), dtype=x.dtype, device=x.device) if want_sum else None
+        out = torch.empty((rows, Cc), dtype=_odt(x), device=x.device)
+    xsum = torch.empty((rows, Cc), dtype=x.dtype, device=x.device) if want_sum else None      # fp32 stream in -> fp32 sum out (it continues the stream)
     check(_lib.svd_layernorm(_p(x), ld, _p(out), out.stride(0), rows, Cc, _p(gamma), _p(beta), float(eps),
                              _p(addvec), addvec.stride(0) if addvec is not None else 0, rows_per_vec,
-                             _p(xsum), xsum.stride(0) if xsum is not None else 0, int(silu), _dt(x), _stream()),
+                             _p(xsum), xsum.stride(0) if xsum is not None else 0, int(silu), _dt_in(x), _stream()),
           "svd_layernorm")
     return (out, xsum) if want_sum else out
 
@@ -300,17 +328,53 @@ def tokens_to_nchw(x, c, frames, h, w):
 
 
 def concat_channels(a, b):
+    """torch.cat((a, b), channels) -> 16-bit [rows, ca + cb].  fp32 inputs (the residual stream and the encoder's skip tensors) are rounded
+    to the element type on the way: the concatenation is a GEMM operand (skip_connection) and a GroupNorm input."""
     rows = a.shape[0]
+    if a.dtype == torch.float32 or b.dtype == torch.float32:
+        out = torch.empty((rows, a.shape[1] + b.shape[1]), dtype=ELEM, device=a.device)
+        to_elem_rows(a, out=out[:, :a.shape[1]])
+        to_elem_rows(b, out=out[:, a.shape[1]:])
+        return out
     out = torch.empty((rows, a.shape[1] + b.shape[1]), dtype=a.dtype, device=a.device)
     check(_lib.svd_concat_channels(_p(a), a.stride(0), a.shape[1], _p(b), b.stride(0), b.shape[1], _p(out),
                                    out.stride(0), rows, _stream()), "svd_concat_channels")
     return out
 
 
+def to_elem_rows(x, out=None):
+    """[rows, C] fp32 (row stride free) -> 16-bit element type, vectorised; 16-bit input: copied into `out` or returned as is."""
+    rows, ld = _rows_ld(x)
+    if x.dtype != torch.float32:
+        if out is None:
+            return x
+        out.copy_(x)
+        return out
+    if out is None:
+        out = torch.empty((rows, x.shape[1]), dtype=ELEM, device=x.device)
+    assert out.shape == x.shape and out.stride(1) == 1
+    check(_lib.svd_cast_rows_f32(_p(x), ld, _p(out), out.stride(0), rows, x.shape[1], _dt(out), _stream()), "svd_cast_rows_f32")
+    return out
+
+
 def add_rows(x, b):
+    """x + b row-wise; x may be the fp32 residual stream (then the sum is fp32), b is 16 bit."""
     out = torch.empty_like(x)
+    dt = (_dt(b) | _l.DTYPE_IN_F32) if x.dtype == torch.float32 else _dt(x)
     check(_lib.svd_add_rows(_p(x), x.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1],
-                            _dt(x), _stream()), "svd_add_rows")
+                            dt, _stream()), "svd_add_rows")
+    return out
+
+
+def permute_rows(x, dims, perm, out=None):
+    """x viewed as rows [d0, d1, d2, d3, C] -> the same rows ordered [d_perm0, d_perm1, d_perm2, d_perm3, C] (one pass, 16-byte vectors)."""
+    assert x.is_contiguous() and len(dims) == 4 and len(perm) == 4
+    n = dims[0] * dims[1] * dims[2] * dims[3]
+    assert x.shape[0] == n and (x.shape[1] * x.element_size()) % 16 == 0
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.svd_permute_rows(_p(x), _p(out), *[int(d) for d in dims], *[int(q) for q in perm], x.shape[1] * x.element_size(), _stream()),
+          "svd_permute_rows")
     return out
 
 

@@ -122,6 +122,13 @@ class CfgPairExchange:
         return torch.cat(parts, 0)
 
 
+def _permute_rows(x, dims, perm):
+    """Rows [d0 d1 d2 d3, C] -> rows ordered by `perm` (the repack either side of the sequence-parallel all-to-all): ONE HIP kernel pass
+    (svd_permute_rows) instead of torch's generic strided copy."""
+    from . import ops
+    return ops.permute_rows(x.contiguous(), dims, perm)
+
+
 def split_sizes(n, parts):
     """Contiguous near-even split of n items into `parts` ranges: the first n % parts ranges get one more (25 frames / 4 -> 7 6 6 6)."""
     q, r = divmod(n, parts)
@@ -170,9 +177,9 @@ class SeqParallel:
         S, C = self.size, x.shape[1]
         cnt, pl = self.frame_counts(T), self.pix_local(pix)
         tl = cnt[self.rank]
-        send = x.reshape(B, tl, S, pl, C).permute(2, 0, 1, 3, 4).contiguous()            # [dest][b][t_local][pixel_local][c]
+        send = _permute_rows(x, (B, tl, S, pl), (2, 0, 1, 3))                              # [dest][b][t_local][pixel_local][c], one pass
         recv = torch.empty((B * T * pl, C), dtype=x.dtype, device=x.device)
-        all_to_all_single(recv, send.reshape(-1, C), [B * c * pl for c in cnt], [B * tl * pl] * S, group=self.group)
+        all_to_all_single(recv, send, [B * c * pl for c in cnt], [B * tl * pl] * S, group=self.group)
         if B == 1:
             return recv                                                                   # source order == frame order
         parts = recv.split([B * c * pl for c in cnt], 0)
@@ -188,9 +195,9 @@ class SeqParallel:
         else:
             xs = x.reshape(B, T, pl, C).split(cnt, 1)
             send = torch.cat([p.reshape(-1, C) for p in xs], 0)
-        recv = torch.empty((S, B, tl, pl, C), dtype=x.dtype, device=x.device)             # [source = pixel range][b][t_local][pixel_local]
-        all_to_all_single(recv.reshape(-1, C), send, [B * tl * pl] * S, [B * c * pl for c in cnt], group=self.group)
-        return recv.permute(1, 2, 0, 3, 4).reshape(B * tl * pix, C)
+        recv = torch.empty((S * B * tl * pl, C), dtype=x.dtype, device=x.device)          # [source = pixel range][b][t_local][pixel_local]
+        all_to_all_single(recv, send, [B * tl * pl] * S, [B * c * pl for c in cnt], group=self.group)
+        return _permute_rows(recv, (S, B, tl, pl), (1, 2, 0, 3))                          # [b][t_local][pixel range][pixel_local] = frame layout
 
     # ---- small collectives ---------------------------------------------------------------------------------------------------------
     def allreduce_sums(self, sums):

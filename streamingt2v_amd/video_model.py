@@ -141,12 +141,13 @@ class VideoResBlock:
             et_pre = (emb_out[0] if sp is None else emb_out[1])[:, self.et_off:self.et_off + self.cout]
         cv_in = dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F)
         cv = dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F)
+        st = ops.STREAM_F32           # the block's input / intermediate sum / output are the residual stream: fp32 between kernels when set
         h = ops.groupnorm(x, F, pix, self.n1w, self.n1b, 1e-5, silu=True)
         e = e_pre if e_pre is not None else ops.gemm(emb_silu, self.we, bias=self.be, out_f32=True)
         h = ops.gemm(h, self.w1, bias=self.b1, rowvec=e, rows_per_vec=pix, conv=cv_in)
         h = ops.groupnorm(h, F, pix, self.n2w, self.n2b, 1e-5, silu=True)
-        skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
-        hs = ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=cv)
+        skip = x if self.cin == self.cout else ops.gemm(ops.to_elem_rows(x), self.ws, bias=self.bs, out_f32=st)
+        hs = ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=cv, out_f32=st)
         if sp is None:
             # time_stack: 5-D GroupNorm statistics pool over the T frames of a batch element (video_model.py:75-80)
             tv = dict(cin=self.cout, T=T, pix=pix)
@@ -155,7 +156,7 @@ class VideoResBlock:
             g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pix, temporal=tv)
             g = ops.groupnorm(g, F, pix, self.tn2w, self.tn2b, 1e-5, frames_per_stat=T, silu=True)
             # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip)
-            return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(self.alpha, hs), temporal=tv)
+            return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(self.alpha, hs), temporal=tv, out_f32=st)
         # sequence parallel: the whole time_stack in the PIXEL layout (all T frames of this rank's pixel range); its two norms pool
         # over every frame and pixel -> all-reduce of the sums
         B = (emb_out[1] if emb_out is not None else emb_full).shape[0] // T
@@ -167,7 +168,7 @@ class VideoResBlock:
         et = et_pre if et_pre is not None else ops.gemm(emb_full, self.twe, bias=self.tbe, out_f32=True)
         g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pl, temporal=tv)
         g = _gn_pooled(g, B * T, pl, self.tn2w, self.tn2b, 1e-5, T, cnt, sp, True)
-        out = ops.gemm(g, self.tw2, bias=self.tb2, residual=hp, blend=(self.alpha, hp), temporal=tv)
+        out = ops.gemm(g, self.tw2, bias=self.tb2, residual=hp, blend=(self.alpha, hp), temporal=tv, out_f32=st)
         return sp.to_frames(out, B, T, pix)
 
 
@@ -341,62 +342,65 @@ class SpatialVideoTransformer:
         (parallel.SeqParallel) x / ctx hold this rank's frames; the temporal block runs in the pixel layout."""
         c, heads, pix = self.c, self.heads, H * W
         M, B = F * pix, tctx.shape[0]
+        st = ops.STREAM_F32           # fp32 residual stream: x, h, xm are fp32 between the kernels; every GEMM / attention operand is 16 bit
+        e16 = ops.ELEM if x.dtype == torch.float32 else x.dtype
         tctx_tokens = None
         if ctx.dim() == 3:                     # APM: [F, 17, 1024] tokens (fp32); tctx [B, 17, 1024]
             if not self.use_apm:
                 raise NotImplementedError("cross-attention contexts with > 1 token need use_apm (config.yaml:115 ships use_apm: false)")
             tctx_tokens, ctx = tctx, self._apm_context(ctx)
         h = ops.groupnorm(x, F, pix, self.nw, self.nb, 1e-6, silu=False)
-        h = ops.gemm(h, self.wpi, bias=self.bpi)
+        h = ops.gemm(h, self.wpi, bias=self.bpi, out_f32=st)
         # ---- spatial BasicTransformerBlock (attention.py:567-593) ----
         n1 = ops.layernorm(h, *self.s_ln["norm1"])
         qk = ops.gemm(n1, self.s_wqk)
-        vt, tok_ld = self._vt_buf(F, pix, x.dtype)
+        vt, tok_ld = self._vt_buf(F, pix, e16)
         ops.gemm(n1, self.s_wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
-        a = torch.empty((M, c), dtype=x.dtype, device=x.device)
+        a = torch.empty((M, c), dtype=e16, device=x.device)
         ops.attn_spatial(qk[:, :c], qk[:, c:], vt, a, F, pix, heads)
         v2, v2t_c = self._attn2_const(ctx, tctx if tctx_tokens is None else None)                    # attn2 == const/frame
-        h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h)
+        h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h, out_f32=st)
         n3 = ops.layernorm(h, *self.s_ln["norm3"])
         g = ops.gemm(n3, self.s_wf1, bias=self.s_bf1, geglu=True)
-        h = ops.gemm(g, self.s_wf2, bias=self.s_bf2, residual=h)          # x_spatial
+        h = ops.gemm(g, self.s_wf2, bias=self.s_bf2, residual=h, out_f32=st)          # x_spatial
         # ---- temporal VideoTransformerBlock on the same token layout (video_attention.py:125-168) ----
         # rows (b, t, pixel) with pt pixels per frame: all of them, or this rank's pixel range of ALL T frames (one all-to-all in)
         ht, pt = (h, pix) if sp is None else (sp.to_pixels(h, B, T, pix), sp.pix_local(pix))
         nin, xm = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=self._time_emb(B * T, T), rows_per_vec=pt, want_sum=True)
         g = ops.gemm(nin, self.t_wi1, bias=self.t_bi1, geglu=True)
-        xm = ops.gemm(g, self.t_wi2, bias=self.t_bi2, residual=xm)
+        xm = ops.gemm(g, self.t_wi2, bias=self.t_bi2, residual=xm, out_f32=st)
         n1 = ops.layernorm(xm, *self.t_ln["norm1"])
         qkv = ops.gemm(n1, self.t_wqkv)
-        at = torch.empty((B * T * pt, c), dtype=x.dtype, device=x.device)
+        at = torch.empty((B * T * pt, c), dtype=e16, device=x.device)
         ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pt, heads)
         if tctx_tokens is None:
             v2t = v2t_c                                                                               # [B, C]
-            xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm)
+            xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm, out_f32=st)
         else:
             # APM: attn2 of the temporal block is a real cross-attention of every (frame, pixel) token to the n_tok context tokens of its
             # batch element (video_attention.py:150-154 with time_context = context[::T] repeated over pixels)
-            xm = ops.gemm(at, self.t_wo, bias=self.t_bo, residual=xm)
+            xm = ops.gemm(at, self.t_wo, bias=self.t_bo, residual=xm, out_f32=st)
             nt = tctx_tokens.shape[1]
             tk = ops.to_bf16(tctx_tokens.float().reshape(B * nt, -1).contiguous())
             q2 = ops.gemm(ops.layernorm(xm, *self.t_ln["norm2"]), self.t_wq2)
             k2 = ops.gemm(tk, self.t_wk2)
-            key = (B, x.dtype)
+            key = (B, e16)
             vt2 = self._vt2.get(key)
             if vt2 is None:
-                vt2 = self._vt2[key] = torch.zeros((B, c, 64), dtype=x.dtype, device=x.device)
+                vt2 = self._vt2[key] = torch.zeros((B, c, 64), dtype=e16, device=x.device)
             # V^T [B, C, 64]: 17 tokens per batch element are not a multiple of the 4-token store width of the GEMM's transposed-output
             # mode, so the (tiny: B x 17 x C) transpose is a copy here
             vt2[:, :, :nt] = ops.gemm(tk, self.t_wv2).view(B, nt, c).transpose(1, 2)
-            a2 = torch.empty((B * T * pt, c), dtype=x.dtype, device=x.device)
+            a2 = torch.empty((B * T * pt, c), dtype=e16, device=x.device)
             ops.attn_cross(q2, k2, vt2, a2, B, T * pt, nt, 1, heads)
-            xm = ops.gemm(a2, self.t_wo2, bias=self.t_bo2, residual=xm)
+            xm = ops.gemm(a2, self.t_wo2, bias=self.t_bo2, residual=xm, out_f32=st)
         n3 = ops.layernorm(xm, *self.t_ln["norm3"])
         g = ops.gemm(n3, self.t_wf1, bias=self.t_bf1, geglu=True)
         xb = ops.gemm(g, self.t_wf2, bias=self.t_bf2, residual=xm, blend=(self.alpha, ht))     # AlphaBlender
         if sp is not None:
             xb = sp.to_frames(xb, B, T, pix)                                                    # one all-to-all out
-        return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x)
+        # xb (the blend) is consumed by proj_out only: a GEMM operand, 16 bit; proj_out + x continues the stream
+        return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out_f32=st)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -429,6 +433,8 @@ class ConditionalModel:
         this rank's frames, the 7 conditioning frames' K / V are all-gathered (they are sharded like the ControlNet that made them), and
         the 5-D GroupNorm sums are all-reduced."""
         c, pix = self.c, H * W
+        cond = ops.to_elem_rows(cond)          # ControlNet features: a GEMM operand here (16-bit copy of the ControlNet's fp32 stream)
+        e16 = cond.dtype
         if sp is None:
             B = F // T
             hn = ops.groupnorm(sample, F, pix, self.nw, self.nb, 1e-6, frames_per_stat=T, silu=False)
@@ -442,11 +448,11 @@ class ConditionalModel:
         kv = ops.gemm(cond, self.wkv)
         if sp is not None:
             kv = sp.gather_frames(kv, B, Tc, pix)
-        a = torch.empty((F * pix, c), dtype=sample.dtype, device=sample.device)
+        a = torch.empty((F * pix, c), dtype=e16, device=sample.device)
         ops.attn_temporal(q, kv[:, :c], kv[:, c:], a, B, Tq, Tc, pix, self.heads)
         a = ops.gemm(a, self.wo, bias=self.bo)
         # dropout(p=.25) on the non-conditional frames is identity in eval mode (conditioning.py:74-75)
-        return ops.gemm(a, self.wpo, bias=self.bpo, residual=sample)
+        return ops.gemm(a, self.wpo, bias=self.bpo, residual=sample, out_f32=sample.dtype == torch.float32)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -473,7 +479,7 @@ class _Conv:
         else:
             ho, wo = H, W
         cv = dict(cin=self.cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=self.stride, ups=self.ups, frames=F)
-        return ops.gemm(x, self.w, bias=self.b, conv=cv, **kw), ho, wo
+        return ops.gemm(ops.to_elem_rows(x), self.w, bias=self.b, conv=cv, **kw), ho, wo
 
 
 class _EmbedMLP:
@@ -592,7 +598,7 @@ class _EncoderBase:
             elif isinstance(m, SpatialVideoTransformer):
                 h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp)
             else:
-                h, H, W = m.forward(h, F, H, W)
+                h, H, W = m.forward(h, F, H, W, out_f32=ops.STREAM_F32)      # stem / Downsample / Upsample convolutions write the stream
         return h, H, W
 
     def _local_conditioning(self, timesteps, context, y, T, sp):

@@ -177,6 +177,24 @@ def add_rows(x, b):
     return (x.float() + b.float()).to(x.dtype)
 
 
+def to_elem_rows(x, out=None):
+    from streamingt2v_amd import ops
+    y = x.to(ops.ELEM)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def permute_rows(x, dims, perm, out=None):
+    C = x.shape[1]
+    y = x.reshape(*dims, C).permute(*perm, 4).reshape(-1, C).contiguous()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def to_elem(x, silu=False):
     from streamingt2v_amd import ops
     return (F.silu(x) if silu else x).to(ops.ELEM)
@@ -202,7 +220,7 @@ def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
 
 
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
-         "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "timestep_embedding", "edm_euler_step")
+         "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step")
 
 
 def install(monkeypatch=None):
