@@ -604,6 +604,8 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
                     help="16-bit element type of the kernels (fp32 accumulation either way, same MFMA rate): fp16 (default) = the reference's "
                          "own autocast precision (config.yaml:8), the one the parity tests assert north_star's tolerance in; bf16 selectable")
+    ap.add_argument("--residual-stream", default=None, choices=["fp32", "16"],
+                    help="residual stream of the UNet / ControlNet between kernels (default: the package default, streamingt2v_amd.ops.STREAM_F32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true")
     args = ap.parse_args()
@@ -627,6 +629,8 @@ def main():
     from streamingt2v_amd.streaming_svd import StreamingSVD
     parallel.init_from_env(backend="gloo" if share else "nccl", device=device)
     ops.set_element_dtype(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
+    if args.residual_stream is not None:
+        ops.set_stream_f32(args.residual_stream == "fp32")
     if args.workload == "stage1":
         return run_stage1(args, rank, world, device)
     if args.workload == "full":

@@ -214,10 +214,11 @@ class AutoencodingEngineDecoder:
     def decode(self, z, **kwargs):
         return self.decoder.forward(z, **kwargs)
 
-    @staticmethod
-    def output_shape(z):
-        """decoded frames of latents z [n, 4, h, w]: [n, 3, 8h, 8w]."""
-        return (z.shape[0], 3, 8 * z.shape[2], 8 * z.shape[3])
+    def output_shape(self, z):
+        """decoded frames of latents z [n, 4, h, w]: [n, 3, f h, f w] with f = 2^(levels - 1) (8 for the shipped 4-level decoder).  Used by
+        the frame-group-sharded decode on ranks that own no group (found by tests/test_gpu_multiproc.py: a 2-level decoder is not 8x)."""
+        f = 2 ** (len(self.decoder.cfg.ch_mult) - 1)
+        return (z.shape[0], self.decoder.cfg.out_ch, f * z.shape[2], f * z.shape[3])
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

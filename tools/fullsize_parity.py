@@ -30,7 +30,9 @@ def frame_errors(out, ref):
     return dict(abs_max=e.max().item(), abs_mean=e.mean().item(), rel_max=(e / r).max().item(), ref_rms=r.mean().item(), corr=corr)
 
 
-def wrapper_fullsize(dtype, device="cuda", sds=None):
+def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=False):
+    """stream_f32: None = the package default (ops.STREAM_F32), True / False = fp32 / 16-bit residual stream.  timing: also time the forward
+    (3 runs after the parity run, device-synchronised) -> res['ms']."""
     from oracle.cases import FULLSIZE_CASE as c, fullsize_inputs
     from streamingt2v_amd import ops
     from streamingt2v_amd.params import init_by_name
@@ -38,6 +40,9 @@ def wrapper_fullsize(dtype, device="cuda", sds=None):
     from streamingt2v_amd.wrappers import StreamingWrapper
     torch.set_grad_enabled(False)
     ops.set_element_dtype(DT[dtype])
+    prev_stream = ops.STREAM_F32
+    if stream_f32 is not None:
+        ops.set_stream_f32(stream_f32)
     gold = torch.load(os.path.join(GOLD, "wrapper_fullsize.pt"))
     cfg = UNetConfig()
     unet, cn = VideoUNet(cfg), ControlNet(cfg)
@@ -54,6 +59,16 @@ def wrapper_fullsize(dtype, device="cuda", sds=None):
                        image_only_indicator=torch.zeros(2, T, device=device), ctrl_frames=inp["ctrl_frames"])
     torch.cuda.synchronize()
     res = frame_errors(out, gold["out"])
+    res["stream_f32"] = ops.STREAM_F32
+    if timing:
+        import time
+        t0 = time.perf_counter()
+        for _ in range(3):
+            wrap.forward(inp["x"], inp["t"], {k: inp[k] for k in ("concat", "crossattn", "vector")}, batch_size=2, num_video_frames=T,
+                         image_only_indicator=torch.zeros(2, T, device=device), ctrl_frames=inp["ctrl_frames"])
+        torch.cuda.synchronize()
+        res["ms"] = (time.perf_counter() - t0) / 3 * 1e3
+    ops.set_stream_f32(prev_stream)
     del unet, cn, wrap
     torch.cuda.empty_cache()
     return res
@@ -84,6 +99,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="both")
     ap.add_argument("--which", default="both")
+    ap.add_argument("--stream", default="default", choices=["default", "fp32", "16", "both"], help="residual stream of the wrapper: fp32 / 16 bit / both")
+    ap.add_argument("--timing", action="store_true")
     a = ap.parse_args()
     sds = {}
     for name in ("fp16", "bf16"):
@@ -94,9 +111,11 @@ def main():
             print(f"[full-size VideoDecoder 2 frames @576x1024 vs reference, {name}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | "
                   f"rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | corr {r['corr']:.7f}", flush=True)
         if a.which in ("both", "wrapper"):
-            r = wrapper_fullsize(name, sds=sds)
-            print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, {name}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | "
-                  f"rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | corr {r['corr']:.7f}", flush=True)
+            for st in {"default": [None], "fp32": [True], "16": [False], "both": [True, False]}[a.stream]:
+                r = wrapper_fullsize(name, sds=sds, stream_f32=st, timing=a.timing)
+                print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, {name}, residual stream {'fp32' if r['stream_f32'] else '16 bit'}] "
+                      f"per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | "
+                      f"corr {r['corr']:.7f}" + (f" | forward {r['ms']:.1f} ms" if "ms" in r else ""), flush=True)
 
 
 if __name__ == "__main__":
