@@ -1,0 +1,61 @@
+"""The reference-side swap of INTEGRATION.md section 1 as code: put the MI355X hot path inside the reference's own StreamingSVD object.
+
+The reference's `StreamingSVD` (code/diffusion_trainer/streaming_svd.py) and `AutoencodingEngine` (sgm/models/autoencoder.py) are
+`torch.nn.Module`s and `inference_model` / `first_stage_model.decoder` are REGISTERED child modules: assigning a plain object to them raises
+`TypeError: cannot assign ... as child module` (found by executing the swap, tests/test_dropin_reference.py).  The mirrors in this package are
+plain Python objects (they own packed device tensors, not nn.Parameters), so the swap goes through `HipModule`, a parameter-less nn.Module
+that forwards `forward(...)` and attribute reads to the object it wraps:
+
+    from streamingt2v_amd import dropin
+    dropin.install(self.model)            # end of inference_i2v.StreamingPipeline.init_model(), after the strict checkpoint load (:125-141)
+
+After it, the reference's unmodified `_generate_conditional_output` / `Denoiser` / `EulerEDMSampler` / `decode_first_stage` drive
+`StreamingWrapper.forward(x * c_in, c_noise, cond, batch_size=, num_video_frames=, image_only_indicator=, ctrl_frames=)`
+(denoiser.py:36-38, wrappers.py:23-78) and `decoder(z, timesteps=n)` (autoencoder.py:210-212) on libsvdhip.so.
+"""
+import sys
+
+import torch.nn as nn
+
+
+class HipModule(nn.Module):
+    """nn.Module shell around one of this package's objects (StreamingWrapper, VideoDecoder, I2VGenXLUNet): no parameters, `forward` and
+    every other attribute come from the wrapped object."""
+
+    def __init__(self, impl):
+        super().__init__()
+        object.__setattr__(self, "impl", impl)
+
+    def forward(self, *args, **kwargs):
+        return self.impl.forward(*args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.__dict__["impl"], name)
+
+
+class VideoDecoderModule(HipModule):
+    """The class `decode_first_stage` tests with isinstance(self.first_stage_model.decoder, VideoDecoder) (streaming_svd.py:138) to decide
+    whether to pass `timesteps=`: `install` rebinds the module-level name `VideoDecoder` of the reference's streaming_svd.py to this class."""
+
+
+def install(model, device="cuda", unet_cfg=None, vae_cfg=None, state_dict=None):
+    """model: the reference's StreamingSVD module AFTER its strict checkpoint load.  Builds the MI355X mirrors from the same weights
+    (`model.diffusion_model.*`, `controlnet.*`, `first_stage_model.decoder.*`; strict) and swaps the two hot-path objects in place.
+    Returns (wrapper, decoder): the wrapped streamingt2v_amd objects."""
+    from .temporal_ae import VaeConfig, VideoDecoder
+    from .video_model import ControlNet, UNetConfig, VideoUNet
+    from .wrappers import StreamingWrapper
+    sd = state_dict if state_dict is not None else model.state_dict()
+    unet = VideoUNet(unet_cfg or UNetConfig()).load_state_dict(sd, device=device, prefix="model.diffusion_model.")
+    cnet = ControlNet.from_unet(unet).load_state_dict(sd, device=device, prefix="controlnet.")
+    dec = VideoDecoder(vae_cfg or VaeConfig()).load_state_dict(sd, device=device, prefix="first_stage_model.decoder.")
+    wrapper = StreamingWrapper(diffusion_model=unet, controlnet=cnet, num_frame_conditioning=model.inference_params.num_conditional_frames)
+    model.inference_model = HipModule(wrapper)
+    model.first_stage_model.decoder = VideoDecoderModule(dec)       # AutoencodingEngine.decode() keeps calling self.decoder(z, timesteps=n)
+    ref_module = sys.modules.get(type(model).__module__)
+    if ref_module is not None and hasattr(ref_module, "VideoDecoder"):
+        ref_module.VideoDecoder = VideoDecoderModule                 # the isinstance at streaming_svd.py:138
+    return wrapper, dec

@@ -177,6 +177,20 @@ def add_rows(x, b):
     return (x.float() + b.float()).to(x.dtype)
 
 
+def softmax_rows(s, out, scale):
+    out.copy_(torch.softmax(s.float() * scale, dim=-1).to(out.dtype))
+    return out
+
+
+def ae_time_mix3(x, w, b, frames, h, wd, clamp):
+    """AE3DConv.time_mix_conv (temporal_ae.py:99-105): 3-tap conv over frames on the 3 output channels, zero padded; x [frames*h*wd, >=3]
+    tokens fp32, w [3, 3, 3] (co, ci, kt) -> NCHW fp32."""
+    v = x.float()[:, :3].reshape(1, frames, h * wd, 3).permute(0, 3, 1, 2)[..., None]            # b c t p 1
+    y = F.conv3d(v, w.float()[..., None, None], b.float(), padding=(1, 0, 0))[0, :, :, :, 0]      # c t p
+    y = y.permute(1, 0, 2).reshape(frames, 3, h, wd)
+    return y.clamp(-1.0, 1.0) if clamp else y.contiguous()
+
+
 def to_elem_rows(x, out=None):
     from streamingt2v_amd import ops
     y = x.to(ops.ELEM)
@@ -220,7 +234,7 @@ def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
 
 
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
-         "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step")
+         "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3")
 
 
 def install(monkeypatch=None):
