@@ -1,0 +1,153 @@
+"""tests/golden/ar_autocast_envelope.pt -- what the REFERENCE'S OWN production precision does end to end (build container only).
+
+    python oracle/make_golden_autocast_envelope.py [--steps 2 30]
+
+The reference ships `precision: 16-mixed` (config.yaml:8): the UNet / ControlNet forward runs under torch.autocast(float16); the VAE decode
+does not (`disable_first_stage_autocast: true`, config.yaml:310).  Round 2's end-to-end tolerances of tests/test_gpu_ar_parity.py were
+hand-widened numbers; this script replaces them by a MEASUREMENT: the unmodified reference networks (VideoUNet, ControlNet, StreamingWrapper,
+VideoDecoder), its own EulerEDMSampler / Denoiser / guider / discretizations, run through the case of tests/test_gpu_ar_parity.py
+
+    chunk 0 (UNet without control, EDM/Karras sigmas, guidance 1 -> 3) -> decode -> clamp -> PIL 1/255 grid
+    2 x [control frames = last Tc decoded frames, anchor = chunk0[6] -> conditioner -> sampler (AYS, guidance 1.5 -> 3) -> decode -> clamp -> keep [Tc:]]
+
+once in fp32 and once with every network evaluation under torch.autocast("cpu", dtype=float16), on identical noise.  Stored per step count:
+the fp32 video on a stride-2 pixel subset (the golden the GPU test compares the HIP path against directly -- the REFERENCE's output, not only
+the oracle's), and the
+envelope = per-chunk per-frame L2 (max / mean) and the uint8 level statistics of autocast-vs-fp32.  The GPU test asserts that the HIP path
+deviates from the reference's fp32 video by no more than the reference's own 16-mixed execution does.
+The outer-loop glue (PIL grid, control-frame range conversion, result[Tc:]) is taken from the product's static helpers, which
+tests/golden/ar_loop_tiny.pt pins bit for bit against the reference's unmodified `_autoregressive_generation`.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_bootstrap  # noqa: E402
+
+ref_bootstrap.install()
+from oracle import cases  # noqa: E402
+from streamingt2v_amd.params import Spec, init_by_name  # noqa: E402
+from streamingt2v_amd.streaming_svd import StreamingSVD  # noqa: E402
+
+TV = dict(ch=32, ch_mult=(1, 2, 2, 2), num_res_blocks=1)          # the 4-level tiny decoder of tests/test_gpu_ar_parity.py
+
+
+def load_by_name(module, seed):
+    s = Spec()
+    for k, v in module.state_dict().items():
+        s.add(k, *v.shape)
+    module.load_state_dict(init_by_name(s, seed=seed), strict=True)
+    return module
+
+
+def case_inputs():
+    """identical to the fixture of tests/test_gpu_ar_parity.py"""
+    tu = cases.TINY_UNET
+    T = tu["T"]
+    g = torch.Generator(); g.manual_seed(2718)
+    noises = [torch.randn(T, 4, tu["h"], tu["w"], generator=g) for _ in range(3)]
+    image = torch.rand(3, 8 * tu["h"], 8 * tu["w"], generator=g) * 2 - 1
+    vector = (torch.randn(1, 768, generator=g) * 0.5).repeat(T, 1)
+    return noises, image, vector
+
+
+def conditioner(frame, vector, T):
+    emb, lat = cases.fake_clip_embed(frame[None]), cases.fake_cond_encode(frame[None])
+    c = dict(crossattn=emb[:, None].repeat(T, 1, 1), concat=lat.repeat(T, 1, 1, 1), vector=vector)
+    uc = dict(crossattn=torch.zeros_like(c["crossattn"]), concat=torch.zeros_like(c["concat"]), vector=vector.clone())
+    return c, uc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, nargs="+", default=[2, 30])
+    a = ap.parse_args()
+    torch.set_grad_enabled(False)
+    from models.control.controlnet import ControlNet
+    from models.diffusion.video_model import VideoUNet
+    from models.diffusion.wrappers import StreamingWrapper
+    from models.svd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    from models.svd.sgm.modules.diffusionmodules.denoiser import Denoiser
+    from models.svd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from models.svd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    tu = cases.TINY_UNET
+    T, Tc = tu["T"], tu["Tc"]
+    unet = load_by_name(VideoUNet(**cases.tiny_unet_kwargs()).eval(), 1)
+    cn = load_by_name(ControlNet.from_unet(OpenAIWrapper(unet), merging_mode="addition", zero_conv_mode="Identity", frame_expansion="none",
+                                           downsample_controlnet_cond=True, use_image_encoder_normalization=True, use_controlnet_mask=False,
+                                           condition_encoder="", conditioning_embedding_out_channels=list(tu["cond_embed"])).eval(), 2)
+    dec = load_by_name(VideoDecoder(ch=TV["ch"], out_ch=3, ch_mult=list(TV["ch_mult"]), num_res_blocks=TV["num_res_blocks"], attn_resolutions=[],
+                                    dropout=0.0, in_channels=3, resolution=256, z_channels=4, double_z=True, attn_type="vanilla",
+                                    video_kernel_size=[3, 1, 1]).eval(), 3)
+    wrap = StreamingWrapper(diffusion_model=unet, controlnet=cn, num_frame_conditioning=Tc)
+    den = Denoiser({"target": "models.svd.sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    noises, image, vector = case_inputs()
+    zeros_ioi = torch.zeros(2, T)
+
+    def sampler(steps, disc, min_scale):
+        return EulerEDMSampler(s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, num_steps=steps, verbose=False, device="cpu",
+                               discretization_config=disc,
+                               guider_config={"target": "models.svd.sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                                              "params": {"max_scale": 3.0, "min_scale": min_scale, "num_frames": T}})
+
+    def decode(z):                                               # decode_first_stage: z / 0.18215, groups of 8, fp32 (no autocast, config.yaml:310)
+        z = z.float() / 0.18215
+        return torch.cat([dec(z[i:i + 8], timesteps=len(z[i:i + 8])) for i in range(0, z.shape[0], 8)], 0)
+
+    def run(steps, autocast):
+        import contextlib
+        ac = (lambda: torch.autocast("cpu", dtype=torch.float16)) if autocast else contextlib.nullcontext
+
+        def net_noctrl(x, t, c, **kw):                           # chunk 0: the same VideoUNet without ControlNet / CAM (video_model.py:582,603)
+            with ac():
+                return unet(torch.cat((x, c["concat"]), 1), t, context=c["crossattn"], y=c["vector"], num_video_frames=T,
+                            image_only_indicator=zeros_ioi).float()
+
+        c, uc = conditioner(image, vector, T)
+        s0 = sampler(steps if steps < 25 else 25, {"target": "models.svd.sgm.modules.diffusionmodules.discretizer.EDMDiscretization",
+                                                   "params": {"sigma_min": 0.002, "sigma_max": 700.0, "rho": 7.0}}, 1.0)
+        z = s0(lambda x, s, cc: den(net_noctrl, x, s, cc), noises[0].clone(), cond=c, uc=uc)
+        chunks = [StreamingSVD.quantize_like_pil(decode(z).clamp(-1, 1))]
+        anchor = chunks[0][6]
+        s1 = sampler(steps, {"target": "models.diffusion.discretizer.AlignYourSteps", "params": {"sigma_max": 700.0}}, 1.5)
+        for k in range(2):
+            ctrl = StreamingSVD.extract_ctrl_frames(chunks[-1], Tc)
+            cc, cu = conditioner(anchor, vector, T)
+            add = dict(batch_size=2, num_video_frames=T, image_only_indicator=zeros_ioi, ctrl_frames=ctrl)
+
+            def net(x, t, cd, **kw):
+                with ac():
+                    return wrap(x, t, cd, **kw).float()
+            z = s1(lambda x, s, cd: den(net, x, s, cd, **dict(add)), noises[1 + k].clone(), cond=cc, uc=cu)
+            chunks.append(decode(z).clamp(-1, 1)[Tc:])
+        return torch.cat(chunks, 0)
+
+    from oracle.range_oracle import frames_to_uint8
+    out = {"case": dict(T=T, Tc=Tc, tv=TV, seed=2718), "steps": {}}
+    bounds = [0, T, T + (T - Tc), T + 2 * (T - Tc)]
+    for steps in a.steps:
+        t0 = time.time()
+        ref = run(steps, False)[:, :, ::2, ::2].contiguous()      # every second pixel in both directions: a 4x smaller fixture; all statistics
+        t1 = time.time()                                          # (here and in the GPU test) are taken on this subset
+        amp = run(steps, True)[:, :, ::2, ::2].contiguous()
+        e = (amp - ref).flatten(1).pow(2).mean(1).sqrt()
+        lvl = (frames_to_uint8(amp).int() - frames_to_uint8(ref).int()).abs()
+        env = dict(l2_max=[e[bounds[i]:bounds[i + 1]].max().item() for i in range(3)], l2_mean=[e[bounds[i]:bounds[i + 1]].mean().item() for i in range(3)],
+                   u8_frac_gt1=(lvl > 1).float().mean().item(), u8_frac_gt0=(lvl > 0).float().mean().item(), u8_max=int(lvl.max()))
+        print(f"[reference fp16 autocast vs its own fp32, {steps} steps, chunk 0 + 2 AR chunks] per-frame L2 max per chunk "
+              f"{env['l2_max'][0]:.3e} {env['l2_max'][1]:.3e} {env['l2_max'][2]:.3e} | mean {env['l2_mean'][0]:.3e} {env['l2_mean'][1]:.3e} {env['l2_mean'][2]:.3e} | "
+              f"uint8: {100 * env['u8_frac_gt1']:.3f} % of bytes differ by > 1 level ({100 * env['u8_frac_gt0']:.2f} % by >= 1), max {env['u8_max']} "
+              f"({t1 - t0:.0f} s fp32 + {time.time() - t1:.0f} s autocast)", flush=True)
+        out["steps"][steps] = dict(video_sub=ref.clone(), envelope=env)
+    path = os.path.join(ROOT, "tests", "golden", "ar_autocast_envelope.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,28 @@ def tensor_version(t):
 
 _zeros = {}
 _gn_ws = {}
+# Work log (tools/roofline_table.py): SVD_WORKLOG=<path> makes every launcher below add its algorithmic FLOP / HBM bytes to a per-kernel
+# total for the WHOLE process and dump {kernel key: [launches, flop, bytes]} as JSON at exit.  Run under `rocprofv3 --kernel-trace` the
+# same process gives the device time per kernel name: time and work cover exactly the same dispatches, so TFLOP/s, TB/s and the fraction of
+# the roofline of every kernel can be recomputed from profiles/ alone.  None (default) = no bookkeeping.
+worklog = None
+if __import__("os").environ.get("SVD_WORKLOG"):
+    worklog = {}
+
+    def _dump_worklog(path=__import__("os").environ["SVD_WORKLOG"]):
+        import json
+        with open(path, "w") as f:
+            json.dump(worklog, f)
+    __import__("atexit").register(_dump_worklog)
+
+
+def _wl(key, flops=0.0, nbytes=0.0):
+    e = worklog.get(key)
+    if e is None:
+        e = worklog[key] = [0, 0.0, 0.0]
+    e[0] += 1; e[1] += flops; e[2] += nbytes
+
+
 trace = None   # bench.py installs a per-launch HIP-event recorder here (None = zero overhead)
 tuner = None   # tools/tune_gemm.py installs an in-situ tile autotuner here
 
@@ -197,7 +219,7 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
             if tile_cfg == 0 and sig.endswith("_o1"):       # fp32-stream producer not tuned yet: the ranking of its 16-bit-output twin
                 tile_cfg = _tile_table.get(sig[:-1] + "0", 0)
     args.tile_cfg = tile_cfg
-    if trace is not None:
+    if trace is not None or worklog is not None:
         cfg = tile_cfg or _lib.svd_gemm_pick_config(C.byref(args))
         # algorithmic HBM bytes of this launch: the source activation and the weights read once, the output (and the residual /
         # blend operands) moved once
@@ -206,6 +228,9 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
         src_cols = K if (conv is None and temporal is None) else args.cin
         nbytes = (src_rows * src_cols + N * K) * esz + M * nout * (4 if out.dtype == torch.float32 else esz)
         nbytes += M * nout * (4 if r32 else esz) * ((residual is not None) + (blend is not None))
+        if worklog is not None:
+            _wl(f"gemm|{cfg}|{3 if (args.a_mode == A_CONV3X3 and args.ups) else args.a_mode}|{'f16' if edt == F16 else 'bf16'}", 2.0 * M * N * K, float(nbytes))
+    if trace is not None:
         with trace.launch(f"gemm_cfg{cfg}_mode{args.a_mode}", flops=2.0 * M * N * K, sig=gemm_signature(args), nbytes=float(nbytes)):
             check(_lib.svd_gemm(C.byref(args), _stream()), f"svd_gemm(M={M},N={N},K={K},mode={args.a_mode})")
         return out
@@ -215,6 +240,8 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
 
 def attn_spatial(q, k, vt, out, frames, n_tok, heads):
     """q,k: views into a [frames*n_tok, ld] tensor at the head-0 column; vt: [frames, heads*64, tok_ld]."""
+    if worklog is not None:
+        _wl("attn_spatial_d64_kernel", 4.0 * frames * heads * n_tok * n_tok * 64, 4.0 * frames * n_tok * heads * 64 * 2)
     if trace is not None:
         with trace.launch("attn_spatial_d64", flops=4.0 * frames * heads * n_tok * n_tok * 64, sig=f"attn_spatial_f{frames}_n{n_tok}_h{heads}",
                           nbytes=4.0 * frames * n_tok * heads * 64 * 2):
@@ -227,6 +254,8 @@ def attn_spatial(q, k, vt, out, frames, n_tok, heads):
 
 
 def attn_temporal(q, k, v, out, batch, tq, tk, n_pix, heads):
+    if worklog is not None:       # q, k, v read once + o written once; QK^T and PV flops
+        _wl("attn_temporal", 4.0 * batch * n_pix * heads * tq * tk * 64, 2.0 * batch * n_pix * heads * 64 * (2 * tq + 2 * tk))
     check(_lib.svd_attn_temporal_d64(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
                                      out.stride(0), batch, tq, tk, n_pix, heads, _dt(q), _stream()), "svd_attn_temporal_d64")
     return out
@@ -258,6 +287,9 @@ def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False
     assert rows == frames * pix
     assert frames % frames_per_stat == 0
     partial, stats = _gn_workspace(x.device, frames, Cc, frames // frames_per_stat, groups)
+    if worklog is not None:
+        _wl("gn_stats_partial_kernel", 0.0, float(rows) * Cc * x.element_size())
+        _wl("gn_apply_kernel", 0.0, float(rows) * Cc * (x.element_size() + 2))
     check(_lib.svd_groupnorm_stats(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, float(eps), _p(partial),
                                    _p(stats), _dt_in(x), _stream()), "svd_groupnorm_stats")
     if out is None:
@@ -275,6 +307,8 @@ def groupnorm_sums(x, frames, pix, frames_per_stat, groups=32):
     assert rows == frames * pix and frames % frames_per_stat == 0
     partial, _ = _gn_workspace(x.device, frames, Cc, frames // frames_per_stat, groups)
     sums = torch.empty((frames // frames_per_stat, groups, 2), dtype=torch.float64, device=x.device)
+    if worklog is not None:
+        _wl("gn_stats_partial_kernel", 0.0, float(rows) * Cc * x.element_size())
     check(_lib.svd_groupnorm_sums(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, _p(partial), _p(sums), _dt_in(x), _stream()),
           "svd_groupnorm_sums")
     return sums
@@ -287,6 +321,8 @@ def groupnorm_apply_sums(x, frames, pix, gamma, beta, eps, sums, count, *, frame
     nstat = frames // frames_per_stat
     assert sums.dtype == torch.float64 and sums.is_contiguous() and tuple(sums.shape) == (nstat, groups, 2)
     _, stats = _gn_workspace(x.device, frames, Cc, nstat, groups)
+    if worklog is not None:
+        _wl("gn_apply_kernel", 0.0, float(rows) * Cc * (x.element_size() + 2))
     check(_lib.svd_groupnorm_stats_from_sums(_p(sums), nstat, groups, float(count), float(eps), _p(stats), _stream()),
           "svd_groupnorm_stats_from_sums")
     if out is None:
@@ -302,6 +338,8 @@ def layernorm(x, gamma, beta, *, eps=1e-5, addvec=None, rows_per_vec=0, want_sum
     if out is None:
         out = torch.empty((rows, Cc), dtype=_odt(x), device=x.device)
     xsum = torch.empty((rows, Cc), dtype=x.dtype, device=x.device) if want_sum else None      # fp32 stream in -> fp32 sum out (it continues the stream)
+    if worklog is not None:
+        _wl("layernorm_kernel", 0.0, float(rows) * Cc * (x.element_size() * (2 if want_sum else 1) + 2))
     check(_lib.svd_layernorm(_p(x), ld, _p(out), out.stride(0), rows, Cc, _p(gamma), _p(beta), float(eps),
                              _p(addvec), addvec.stride(0) if addvec is not None else 0, rows_per_vec,
                              _p(xsum), xsum.stride(0) if xsum is not None else 0, int(silu), _dt_in(x), _stream()),
@@ -334,6 +372,9 @@ def concat_channels(a, b):
     """torch.cat((a, b), channels) -> 16-bit [rows, ca + cb].  fp32 inputs (the residual stream and the encoder's skip tensors) are rounded
     to the element type on the way: the concatenation is a GEMM operand (skip_connection) and a GroupNorm input."""
     rows = a.shape[0]
+    if worklog is not None and a.dtype != torch.float32 and b.dtype != torch.float32:
+        _wl("copy_rows_kernel", 0.0, 4.0 * rows * (a.shape[1] + b.shape[1]))
+        _wl("copy_rows_kernel", 0.0, 0.0)            # two launches
     if a.dtype == torch.float32 or b.dtype == torch.float32:
         out = torch.empty((rows, a.shape[1] + b.shape[1]), dtype=ELEM, device=a.device)
         to_elem_rows(a, out=out[:, :a.shape[1]])
@@ -356,6 +397,8 @@ def to_elem_rows(x, out=None):
     if out is None:
         out = torch.empty((rows, x.shape[1]), dtype=ELEM, device=x.device)
     assert out.shape == x.shape and out.stride(1) == 1
+    if worklog is not None:
+        _wl("cast_rows_f32_kernel", 0.0, 6.0 * rows * x.shape[1])
     check(_lib.svd_cast_rows_f32(_p(x), ld, _p(out), out.stride(0), rows, x.shape[1], _dt(out), _stream()), "svd_cast_rows_f32")
     return out
 
@@ -363,6 +406,8 @@ def to_elem_rows(x, out=None):
 def add_rows(x, b):
     """x + b row-wise; x may be the fp32 residual stream (then the sum is fp32), b is 16 bit."""
     out = torch.empty_like(x)
+    if worklog is not None:
+        _wl("add_rows_f32_kernel" if x.dtype == torch.float32 else "add_rows_kernel", 0.0, float(x.numel()) * (2 * x.element_size() + 2))
     dt = (_dt(b) | _l.DTYPE_IN_F32) if x.dtype == torch.float32 else _dt(x)
     check(_lib.svd_add_rows(_p(x), x.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1],
                             dt, _stream()), "svd_add_rows")
@@ -419,6 +464,8 @@ def ae_time_mix3(x, w, b, frames, h, wd, clamp):
 # ---- I2VGen-XL enhancement stage (row A12) ---------------------------------------------------------------------------
 def attn_cross(q, k, vt, out, frames, n_q, n_k, frames_per_kv, heads):
     """q: view at head 0 of [frames*n_q, ld]; k: [(frames/frames_per_kv)*n_k, ld]; vt: [frames/frames_per_kv, heads*64, tok_ld]."""
+    if worklog is not None:
+        _wl("attn_spatial_d64_kernel", 4.0 * frames * heads * n_q * n_k * 64, 2.0 * frames * n_q * heads * 64 * 2)
     args = (_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(out), out.stride(0), frames, n_q, n_k,
             frames_per_kv, heads, _dt(q), _stream())
     if trace is not None:

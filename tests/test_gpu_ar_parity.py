@@ -6,14 +6,20 @@ The conditioner (CLIP tower + VAE encoder; SURVEY N4, pinned elsewhere) is repla
 (oracle/cases.py fake_*), applied to each side's OWN anchor frame, so that every hand-over of the loop (anchor = chunk0[6],
 ctrl_frames = last Tc decoded frames through the reference's range conversion, result[Tc:] kept) feeds back into the numbers.
 
-Tolerances: errors compound over chunks (the decoded frames of chunk k drive the ControlNet of chunk k+1), so the asserted bounds
-are per chunk; measured values are printed.  fp16 is the element type bench.py defaults to.
+Tolerances (round 3): errors compound over chunks (the decoded frames of chunk k drive the ControlNet of chunk k+1), so the bounds are per
+chunk -- and they are no longer hand-picked numbers: tests/golden/ar_autocast_envelope.pt (oracle/make_golden_autocast_envelope.py) holds, for
+exactly this case, (a) the video the UNMODIFIED reference networks / sampler / denoiser produce in fp32 and (b) how far the reference's OWN
+production precision (fp16 autocast of the network evaluations, config.yaml:8) lands from it: per-chunk per-frame L2 and uint8 level
+statistics.  The fp16 HIP path must be at least as close to the reference's fp32 video as the reference's own 16-mixed execution is, with 2
+Euler steps per chunk and with the shipped 25 / 30 steps.  bf16 (selectable, 8x coarser rounding) is held to 8x that envelope.
 """
+import os
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 STEPS = 2
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ar_autocast_envelope.pt")
 
 
 @pytest.fixture(scope="module", params=[torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
@@ -87,7 +93,8 @@ def test_initial_chunk_vs_oracle(world):
     e = _l2(got, ref)
     print(f"[chunk 0 ({STEPS} EDM steps + decode) vs oracle, {w['name']}] per-frame L2 abs max {e.max():.3e} mean {e.mean():.3e}")
     assert torch.isfinite(got).all() and got.shape == ref.shape
-    assert e.max().item() <= (6e-3 if w["is16"] else 4.5e-2)          # measured 3.96e-3 fp16 / 3.15e-2 bf16 (2 steps from sigma 700 + decode)
+    env = torch.load(GOLD)["steps"][STEPS]["envelope"]                  # the reference's own fp16 autocast on this chunk (8x for bf16)
+    assert e.max().item() <= (1.0 if w["is16"] else 8.0) * env["l2_max"][0], (e.max().item(), env["l2_max"][0])
 
 
 def test_autoregressive_chunks_vs_oracle(world):
@@ -118,7 +125,49 @@ def test_autoregressive_chunks_vs_oracle(world):
     lvl = (u8.int() - ref_u8.int()).abs()
     print(f"[AR video: chunk 0 + 2 AR chunks vs oracle, {w['name']}] per-frame L2 abs max per chunk {per_chunk[0]:.3e} {per_chunk[1]:.3e} {per_chunk[2]:.3e}"
           f" | uint8: {100.0 * (lvl > 1).float().mean():.3f} % of bytes differ by > 1 level, max {lvl.max().item()}")
-    # chunk 0 differs only through the 1/255 grid (a rounding flip = 7.8e-3 on single pixels); AR chunks inherit it through the ControlNet
-    tol = (8e-3, 1.5e-2, 2.5e-2) if w["is16"] else (4.5e-2, 8e-2, 1.2e-1)      # measured bf16: 3.2e-2 / 4.9e-2 / 6.6e-2
-    for got_e, t in zip(per_chunk, tol):
-        assert got_e <= t, (per_chunk, tol)
+    # chunk 0 differs only through the 1/255 grid (a rounding flip = 7.8e-3 on single pixels); AR chunks inherit it through the ControlNet.
+    # Bound = what the reference's own fp16 autocast does on this case (committed measurement), 8x for bf16.
+    env = torch.load(GOLD)["steps"][STEPS]["envelope"]
+    k = 1.0 if w["is16"] else 8.0
+    for got_e, t in zip(per_chunk, env["l2_max"]):
+        assert got_e <= k * t, (per_chunk, env["l2_max"])
+    if w["is16"]:
+        assert (lvl > 1).float().mean().item() <= env["u8_frac_gt1"], ((lvl > 1).float().mean().item(), env["u8_frac_gt1"])
+
+
+def _hip_video(w, steps):
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    model = w["model"]
+    c, uc = w["conditioner"](w["image"].cuda())
+    first = StreamingSVD.quantize_like_pil(model._generate_initial_chunk(c, uc, w["noises"][0].cuda(), num_steps=min(steps, 25)))
+    return model._autoregressive_generation(first, w["conditioner"], 2, [n.cuda() for n in w["noises"][1:]], num_steps=steps)
+
+
+@pytest.mark.parametrize("steps", [2, 30])
+def test_video_vs_reference_fp32_within_the_reference_autocast_envelope(world, steps):
+    """The HIP video (chunk 0 + 2 AR hand-overs) against the video of the UNMODIFIED reference networks / sampler / denoiser in fp32
+    (golden), bounded by the deviation of the reference's own fp16-autocast execution from that same video -- with 2 steps per chunk and with
+    the shipped step counts (25 Euler-EDM steps for chunk 0, 30 AlignYourSteps steps per AR chunk)."""
+    from oracle.range_oracle import frames_to_uint8
+    w = world
+    if steps == 30 and not w["is16"]:
+        pytest.skip("the 30-step case runs in the parity element type (fp16)")
+    g = torch.load(GOLD)
+    assert g["case"]["T"] == w["T"] and g["case"]["Tc"] == w["Tc"]
+    ref, env = g["steps"][steps]["video_sub"], g["steps"][steps]["envelope"]
+    video = _hip_video(w, steps)[:, :, ::2, ::2].float().cpu()
+    assert video.shape == ref.shape
+    T, Tc = w["T"], w["Tc"]
+    e = _l2(video, ref)
+    bounds = [0, T, T + (T - Tc), T + 2 * (T - Tc)]
+    per_chunk = [e[bounds[i]:bounds[i + 1]].max().item() for i in range(3)]
+    lvl = (frames_to_uint8(video).int() - frames_to_uint8(ref).int()).abs()
+    frac = (lvl > 1).float().mean().item()
+    print(f"[AR video vs REFERENCE fp32, {steps} steps, {w['name']}] per-frame L2 max per chunk {per_chunk[0]:.3e} {per_chunk[1]:.3e} {per_chunk[2]:.3e} "
+          f"(reference's own fp16 autocast: {env['l2_max'][0]:.3e} {env['l2_max'][1]:.3e} {env['l2_max'][2]:.3e}) | uint8 > 1 level: "
+          f"{100 * frac:.3f} % (reference autocast {100 * env['u8_frac_gt1']:.3f} %), max {lvl.max().item()} ({env['u8_max']})")
+    k = 1.0 if w["is16"] else 8.0
+    for got_e, t in zip(per_chunk, env["l2_max"]):
+        assert got_e <= k * t, (per_chunk, env["l2_max"])
+    if w["is16"]:
+        assert frac <= env["u8_frac_gt1"], (frac, env["u8_frac_gt1"])
