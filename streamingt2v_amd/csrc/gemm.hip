@@ -19,6 +19,7 @@ bool cfg_ok(const svd_gemm_args& a) {
     if (CFG::TRANS != (a.out_mode == SVD_OUT_BF16_T)) return false;
     if ((a.epi_flags & SVD_EPI_GEGLU) && (CFG::FN % 2 != 0)) return false;   // value|gate frag pairs per wave
     if (a.a_mode == SVD_A_CONV3X3 && a.ups && !CFG::UPS_KERNEL) return false; // the folded-upsample kernel exists for a subset of the tiles
+    if ((a.res_f32 || a.out_mode == SVD_OUT_F32) && !CFG::STREAM_KERNEL) return false;   // likewise the fp32-residual-stream kernel
     return true;
 }
 
@@ -97,7 +98,8 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
         if (a.N % 64 != 0 || a.out_mode != SVD_OUT_BF16) return SVD_EINVAL;
     }
     int cfg = a.tile_cfg > 0 ? a.tile_cfg : pick_cfg(a);
-    if (a.tile_cfg > 0 && a.a_mode == SVD_A_CONV3X3 && a.ups && svd_gemm_config_valid(args, cfg) != 1) cfg = pick_cfg(a);   // a tuned table from before the subset
+    if (a.tile_cfg > 0 && ((a.a_mode == SVD_A_CONV3X3 && a.ups) || a.res_f32 || a.out_mode == SVD_OUT_F32) && svd_gemm_config_valid(args, cfg) != 1)
+        cfg = pick_cfg(a);   // a tile of a tuned table that does not carry the folded-upsample / fp32-stream kernel: the heuristic's pick does
     if (svd_gemm_config_valid(args, cfg) != 1) return SVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // the tile table is instantiated in four parts per element type (gemm_cfg.h)

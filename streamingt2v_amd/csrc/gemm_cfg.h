@@ -29,6 +29,12 @@ struct GemmCfg {
     // tiles that also carry the folded-upsample convolution kernel (the Upsample layers of the UNet and of the VAE decoder): the heuristic's
     // picks and the shapes the tuner has chosen for those layers -- not all 22, to bound build time
     static constexpr bool UPS_KERNEL = !TRANS_ && !PP_ && ((BM_ == 128 && (BN_ == 128 || BN_ == 64 || BN_ == 320) && WM_ == 2 && NS_ == 2) || (BM_ == 256 && (BN_ == 128 || BN_ == 256 || BN_ == 320) && WM_ * WN_ == 8 && BK_ == 64));
+    // tiles that also carry the fp32-residual-stream kernel (gemm_impl.inc ST = true): the heuristic's picks and the tiles the tuner chooses for
+    // the stream's producers -- not all 23, to bound build time.  ids 1 2 3 4 5 8 12 14 18 20 21 22
+    static constexpr bool STREAM_KERNEL = !TRANS_ && !PP_ &&
+        ((BM_ == 128 && BN_ == 128 && WM_ == 2 && NS_ == 2 && GLDS_) || (BM_ == 256 && BN_ == 128 && WM_ == 4 && BK_ == 64) ||
+         (BM_ == 128 && BN_ == 64) || (BM_ == 128 && BN_ == 320) || (BM_ == 256 && BN_ == 256 && BK_ == 64 && WM_ * WN_ == 8) ||
+         (BM_ == 64 && BN_ == 128) || (BM_ == 256 && BN_ == 160) || (BM_ == 256 && BN_ == 320));
     // fragment register sets of the k-step software pipeline (gemm_impl.inc compute()): two when accumulators + 2 x fragments leave
     // ~70 registers for addresses / epilogue state inside the wave's share of the 512-entry register file.
     static constexpr int WAVES_PER_SIMD = (THREADS / 256 > MIN_WAVES_PER_SIMD) ? THREADS / 256 : MIN_WAVES_PER_SIMD;

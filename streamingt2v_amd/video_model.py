@@ -125,8 +125,13 @@ class VideoResBlock:
         self.tw1, self.tb1 = _dev_bf16(pack_tconv3(g(t + "in_layers.2.weight")), dev), _dev_f32(g(t + "in_layers.2.bias"), dev)
         self.twe, self.tbe = _dev_bf16(g(t + "emb_layers.1.weight"), dev), _dev_f32(g(t + "emb_layers.1.bias"), dev)
         self.tn2w, self.tn2b = _dev_f32(g(t + "out_layers.0.weight"), dev), _dev_f32(g(t + "out_layers.0.bias"), dev)
-        self.tw2, self.tb2 = _dev_bf16(pack_tconv3(g(t + "out_layers.3.weight")), dev), _dev_f32(g(t + "out_layers.3.bias"), dev)
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))   # image_only_indicator == 0 (util.py:341-357)
+        # AlphaBlender of the block: alpha * x_spatial + (1 - alpha) * x_temporal with x_temporal = x_spatial + conv(...) + bias (the time_stack is a
+        # ResBlock with an identity skip, video_model.py:75-85) = x_spatial + (1 - alpha) * (conv(...) + bias): the blend weight is folded into the
+        # last temporal convolution, which then is a plain "+ residual" GEMM (specialised epilogue, residual prefetched 3 passes ahead) instead of
+        # the generic blend pass with a second full-size operand.  (1 - alpha) * W is rounded to 16 bit once, like W itself.
+        self.tw2 = _dev_bf16(pack_tconv3(g(t + "out_layers.3.weight")) * (1.0 - self.alpha), dev)
+        self.tb2 = _dev_f32(g(t + "out_layers.3.bias").detach().float() * (1.0 - self.alpha), dev)
 
     def forward(self, x, emb_silu, F, T, H, W, sp=None, emb_full=None, emb_out=None):
         """x [F*H*W, C]: the frames this rank holds (all B*T of them without sequence parallelism; then emb_silu is also the
@@ -155,8 +160,8 @@ class VideoResBlock:
             et = et_pre if et_pre is not None else ops.gemm(emb_silu, self.twe, bias=self.tbe, out_f32=True)
             g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pix, temporal=tv)
             g = ops.groupnorm(g, F, pix, self.tn2w, self.tn2b, 1e-5, frames_per_stat=T, silu=True)
-            # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip)
-            return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(self.alpha, hs), temporal=tv, out_f32=st)
+            # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip) = x_spatial + [(1 - alpha) conv + (1 - alpha) bias]  (prepare)
+            return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, temporal=tv, out_f32=st)
         # sequence parallel: the whole time_stack in the PIXEL layout (all T frames of this rank's pixel range); its two norms pool
         # over every frame and pixel -> all-reduce of the sums
         B = (emb_out[1] if emb_out is not None else emb_full).shape[0] // T
@@ -168,7 +173,7 @@ class VideoResBlock:
         et = et_pre if et_pre is not None else ops.gemm(emb_full, self.twe, bias=self.tbe, out_f32=True)
         g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pl, temporal=tv)
         g = _gn_pooled(g, B * T, pl, self.tn2w, self.tn2b, 1e-5, T, cnt, sp, True)
-        out = ops.gemm(g, self.tw2, bias=self.tb2, residual=hp, blend=(self.alpha, hp), temporal=tv, out_f32=st)
+        out = ops.gemm(g, self.tw2, bias=self.tb2, residual=hp, temporal=tv, out_f32=st)
         return sp.to_frames(out, B, T, pix)
 
 

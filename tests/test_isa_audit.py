@@ -29,7 +29,8 @@ def test_k_loops_are_single_blocks_without_scratch(listing):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_isa
     kernels = list(check_isa.kernels(listing))
-    assert len(kernels) == 4                                     # plain, conv3x3, temporal3, conv3x3 with folded upsample
+    assert len(kernels) == 8       # (plain, conv3x3, temporal3, conv3x3 with folded upsample) x (16-bit kernel, fp32-residual-stream kernel)
+    assert sorted(re.search(r"E7ElemF16Lb(\d)E", n).group(1) for n, _ in kernels) == ["0"] * 4 + ["1"] * 4
     for name, body in kernels:
         mode = int(re.search(r"EEELi(\d)E7ElemF16", name).group(1))
         meta = {m.group(1): int(m.group(2)) for m in (re.match(r"^; (\w+): (\d+)", l) for l in body) if m}

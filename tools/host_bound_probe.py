@@ -31,3 +31,38 @@ with torch.no_grad():
         t2 = time.perf_counter()
         print(f"AR chunk: host returned after {t1 - t0:.3f} s, GPU finished after {t2 - t0:.3f} s; {calls['n']} libsvdhip calls "
               f"({(t1 - t0) / max(calls['n'], 1) * 1e6:.1f} us of host time per call)", flush=True)
+
+# ---- part 2: host cost of a launch WITHOUT queue back-pressure -------------------------------------------------------------------------
+# The shipped architecture on a 16x16 latent (kernels of a few microseconds: the GPU drains the queue faster than Python fills it), so the
+# time until forward() returns is pure host work: Python layer logic + ctypes marshalling + hipLaunchKernel.  This is the number that bounds
+# a sequence-parallel rank (1/S of the GPU work behind the SAME number of launches).
+del model, wrapper, vae
+torch.cuda.empty_cache()
+from oracle.cases import FULLARCH_CASE as fc, fullarch_inputs
+from streamingt2v_amd.params import init_by_name
+from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+from streamingt2v_amd.wrappers import StreamingWrapper
+cfg = UNetConfig()
+unet, cn = VideoUNet(cfg), ControlNet(cfg)
+unet.load_state_dict(init_by_name(unet.spec(), seed=33, device="cuda:0"), device="cuda:0")
+cn.load_state_dict(init_by_name(cn.spec(), seed=34, device="cuda:0"), device="cuda:0")
+wrap = StreamingWrapper(unet, cn, fc["Tc"])
+inp = {k: v.cuda() for k, v in fullarch_inputs().items()}
+T = fc["T"]
+kw = dict(batch_size=2, num_video_frames=T, image_only_indicator=torch.zeros(2, T, device="cuda"), ctrl_frames=inp["ctrl_frames"])
+cc = {k: inp[k] for k in ("concat", "crossattn", "vector")}
+with torch.no_grad():
+    for _ in range(3):
+        wrap.forward(inp["x"], inp["t"], cc, **kw)
+    torch.cuda.synchronize()
+    calls["n"] = 0
+    t0 = time.perf_counter()
+    for _ in range(5):
+        wrap.forward(inp["x"], inp["t"], cc, **kw)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+n = calls["n"] / 5
+print(f"shipped architecture on a {fc['h']}x{fc['w']} latent ({2 * T} frames): {n:.0f} libsvdhip calls per forward; host returns after {(t1 - t0) / 5 * 1e3:.1f} ms "
+      f"({(t1 - t0) / 5 / n * 1e6:.1f} us of host time per call), GPU done after {(t2 - t0) / 5 * 1e3:.1f} ms  -> a forward costs >= {(t1 - t0) / 5 * 1e3:.0f} ms of "
+      f"host time whatever the GPU share of a rank is")

@@ -68,7 +68,9 @@ def main():
     ops.tuner = tuner
     ops._tile_table = {}
     t0 = time.time()
-    for workload in ("ar_chunk", "c2"):
+    # both residual-stream forms of the UNet / ControlNet: their producers are different kernels (fp32 stream: `_o1` signatures)
+    for workload, stream in (("ar_chunk", True), ("c2", True), ("ar_chunk", False), ("c2", False)):
+        ops.set_stream_f32(stream)
         wrapper, vae = bench.build_models(workload, dev)
         from streamingt2v_amd.sampling import EulerEDMSampler
         from streamingt2v_amd.streaming_svd import StreamingSVD
@@ -77,9 +79,10 @@ def main():
         with torch.no_grad():
             model._generate_conditional_output(c, uc, ctrl if workload == "ar_chunk" else None, noise)
         torch.cuda.synchronize()
-        print(f"{workload}: {len(tuner.table)} signatures after {time.time() - t0:.0f}s", flush=True)
+        print(f"{workload} (residual stream {'fp32' if stream else '16 bit'}): {len(tuner.table)} signatures after {time.time() - t0:.0f}s", flush=True)
         del wrapper, vae, model
         torch.cuda.empty_cache()
+    ops.set_stream_f32(True)
     # enhancement stage: one I2VGen-XL UNet forward of a 38-frame window (CFG batch 2) at latent 90x160
     from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
     from streamingt2v_amd.params import init_by_name
