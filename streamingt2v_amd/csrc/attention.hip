@@ -15,7 +15,10 @@ namespace {
 //      B-operand fragment of the PV MFMA, matched by one ds_read_b128 of V^T.
 // K and V^T tiles are staged with global_load_lds; swizzle (slot ^= (row>>1)&7) on source address and on read.
 // ------------------------------------------------------------------------------------------------------------
-template <int NW, class E>
+// TPB = KV tiles per LDS buffer and per workgroup barrier.  TPB = 2 (round-3 experiment, the round-2 review's "two KV tiles per barrier"): a
+// buffer holds two tiles (2 x 16 KB), the barrier and the DMA drain come every second tile and the loads run two tiles ahead; 8-wave
+// workgroups only (2 x 64 KB per CU).  Measured slightly SLOWER than TPB = 1 (see the dispatcher): kept as an A/B build, not the default.
+template <int NW, class E, int TPB>
 __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
     const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
     const svd_bf16* __restrict__ Vt, int64_t tok_ld, svd_bf16* __restrict__ O, int64_t ldo,
@@ -26,7 +29,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
     constexpr int TILE_B = KT * 128;       // 8 KiB : [64 rows][64 bf16]
     constexpr int RPP = NT / 8;            // tile rows staged per pass
     constexpr int PASSES = 64 / RPP;       // 2 (NW=4) or 1 (NW=8)
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K tile + Vt tile)
+    constexpr int BUF_B = TPB * 2 * TILE_B;   // one buffer: TPB x (K tile + Vt tile)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 buffers
     const uint32_t smem_base = lds_addr_of(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,8 +65,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
     // staging coordinates
     const int srow = tid >> 3, ps = tid & 7;
     const int ls = ps ^ ((srow >> 1) & 7);
-    auto stage = [&](int kv0, int buf) {
-        const uint32_t dK = __builtin_amdgcn_readfirstlane(smem_base + buf * (2 * TILE_B) + wave * 1024);
+    auto stage = [&](int kv0, int buf, int sub) {
+        const uint32_t dK = __builtin_amdgcn_readfirstlane(smem_base + buf * BUF_B + sub * (2 * TILE_B) + wave * 1024);
         const uint32_t dV = dK + TILE_B;
 #pragma unroll
         for (int j = 0; j < PASSES; ++j) {
@@ -82,13 +86,23 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
     const float c = 0.125f * 1.44269504088896341f;   // d^-0.5 * log2(e)
 
     const int ntiles = (n_tok + KT - 1) / KT;
-    stage(0, 0);
+    const int ngroups = (ntiles + TPB - 1) / TPB;
+    auto stage_group = [&](int g, int buf) {
+#pragma unroll
+        for (int u = 0; u < TPB; ++u)
+            if (g * TPB + u < ntiles) stage((g * TPB + u) * KT, buf, u);
+    };
+    stage_group(0, 0);
     svd_wait_dma();
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntiles) stage((t + 1) * KT, cur ^ 1);
-        const char* sK = smem + cur * (2 * TILE_B);
+    for (int g = 0; g < ngroups; ++g) {
+      const int cur = g & 1;
+      if (g + 1 < ngroups) stage_group(g + 1, cur ^ 1);
+#pragma unroll
+      for (int u = 0; u < TPB; ++u) {
+        const int t = g * TPB + u;
+        if (t >= ntiles) break;                    // wave-uniform: the last group may hold one tile
+        const char* sK = smem + cur * BUF_B + u * (2 * TILE_B);
         const char* sV = sK + TILE_B;
 
         // ---- S^T = K Q^T ----
@@ -186,8 +200,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
                 o_acc[db] = E::mfma(vf, pf, o_acc[db]);
             }
         }
-        svd_wait_dma();
-        __syncthreads();
+      }
+      svd_wait_dma();
+      __syncthreads();
     }
 
     // ---- finalize & store: lane holds query l31, d = 32*db + 8*g + 4*hi + (0..3) ----
@@ -394,15 +409,29 @@ extern "C" int svd_attn_cross_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16
     // be the limit); 4 waves for short sequences (more workgroups, less tail).
     const bool wide = n_q >= 2048;                     // measured: 906-927 vs 876-896 TFLOP/s at 9216 / 14400 tokens
     const int nw = wide ? 8 : 4;
+    // TPB = 2 (two KV tiles per barrier) is built for A/B only (SVD_ATTN_TPB=2): measured 869-879 vs 890-898 TFLOP/s at 9216 tokens and 895-901
+    // vs 907-926 at 14 400 (profiles/r03_attention_tiles_per_barrier.txt) -- with 4 waves per SIMD from two workgroups the barrier of one
+    // workgroup is covered by the other, and the larger buffer only delays the first tile.  Default 1.
+    static const int tpb = [] { const char* e = getenv("SVD_ATTN_TPB"); return (e && e[0] == '2') ? 2 : 1; }();
     const int qblocks = (n_q + nw * 32 - 1) / (nw * 32);
     const int64_t nwg = (int64_t)frames * heads * qblocks;
     if (nwg > 0x7fffffff) return SVD_EINVAL;
-    if (wide)
-        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<8, E>), dim3((unsigned)nwg), dim3(8 * 64), 4 * 8192,
+    if (wide && tpb == 2) {
+        static bool attr_set[2] = {false, false};
+        SVD_DISPATCH_DTYPE(dtype, {
+            if (!attr_set[E::kId == SVD_DTYPE_F16]) {
+                hipFuncSetAttribute((const void*)attn_spatial_d64_kernel<8, E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+                attr_set[E::kId == SVD_DTYPE_F16] = true;
+            }
+            hipLaunchKernelGGL((attn_spatial_d64_kernel<8, E, 2>), dim3((unsigned)nwg), dim3(8 * 64), 8 * 8192,
+                               (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k, frames_per_kv, heads, qblocks);
+        });
+    } else if (wide)
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<8, E, 1>), dim3((unsigned)nwg), dim3(8 * 64), 4 * 8192,
                                                      (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k,
                                                      frames_per_kv, heads, qblocks));
     else
-        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<4, E>), dim3((unsigned)nwg), dim3(4 * 64), 4 * 8192,
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_d64_kernel<4, E, 1>), dim3((unsigned)nwg), dim3(4 * 64), 4 * 8192,
                                                      (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k,
                                                      frames_per_kv, heads, qblocks));
     SVD_CHECK_LAUNCH("attn_spatial_d64");
