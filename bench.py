@@ -18,9 +18,11 @@ chunk: the last AR chunk is cut by [:100], inference_i2v.py:190) / max-over-rank
             blending + frame interpolation; value = 200 final frames / end-to-end seconds, per-stage seconds in config.
 Weights: seeded random at the reference's exact architecture (no checkpoints offline; zero-inits un-zeroed).
 Inputs already resident in HBM when the timed region starts.
-Multi-GPU (--gpus N > 1, default --parallelism job): ONE job strong-scaled -- the two CFG halves over a rank pair (one RCCL
-all-gather of the network output per Euler step) x frame<->pixel sequence parallelism inside each half (RCCL all-to-all around the
-temporal operators; SURVEY.md 8e options 1 + 2).  --parallelism replica: one independent video per GPU (weak scaling, no collective).
+Multi-GPU (--gpus N > 1): default --parallelism auto = N/2 independent videos, each on a CFG PAIR of GPUs (the two CFG halves of every
+network call on two ranks, one RCCL all-gather of the 3.7 MB network output per Euler step; SURVEY.md 8e option 1) -- chunks of one video are
+sequential (chunk k+1 needs chunk k's decoded frames), so more videos, not more chunks, fill a node.  --parallelism job: ONE job strong-scaled
+over all GPUs (CFG pair x frame<->pixel sequence parallelism, RCCL all-to-all around the temporal operators; SURVEY 8e options 1 + 2).
+--parallelism replica: one independent video per GPU (no collective).
 
 The JSON line also carries
   roofline     : dominant kernel (by summed device time) of a SEPARATE traced AR chunk (HIP events around every GEMM / attention
@@ -470,9 +472,8 @@ def run_full(args, rank, world, device):
     pipe.cfg = dict(P.DEFAULTS, enhance_steps=args.denoise_steps or P.DEFAULTS["enhance_steps"])
     pipe.model, pipe.enhancer_unet, pipe.vfi, pipe.device = model, eunet, vfi, device
     pipe.group = None
-    if world > 1 and plan.mode == "job":
-        import torch.distributed as dist
-        pipe.group = dist.group.WORLD
+    if world > 1 and plan.mode in ("job", "pairs"):
+        pipe.group = plan.decode_group          # job: all ranks; pairs: the two ranks of this video
     ge = torch.Generator(); ge.manual_seed(1)
     prompt = (torch.randn(1, 77, 1024, generator=ge), torch.randn(1, 77, 1024, generator=ge))
     image = (np.random.RandomState(7).rand(576, 1024, 3) * 255).astype("uint8")
@@ -602,9 +603,12 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 6 = one whole video for stage1, 1 otherwise)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="stage1", choices=["stage1", "c2", "ar_chunk", "c3", "enhance", "vfi", "full"])
-    ap.add_argument("--parallelism", default="job", choices=["job", "replica", "cfg"],
-                    help="job (stage1): ONE job over all GPUs, CFG pair x frame<->pixel sequence parallelism (strong scaling); "
-                         "replica: one video per GPU (weak scaling, no collective); cfg (c2 / ar_chunk): GPU pairs split the CFG halves of one video")
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "pairs", "job", "replica", "cfg"],
+                    help="auto (default) = pairs on an even number of GPUs, replica otherwise.  pairs: N/2 independent videos, each on a CFG pair of GPUs "
+                         "(one 2-rank all-gather of the network output per Euler step; the only collectives of the default path); job (stage1 / full): ONE "
+                         "job over all GPUs, CFG pair x frame<->pixel sequence parallelism (all-to-all around the temporal operators; strong scaling; "
+                         "verified on the HIP kernels with 2 and 4 processes, tests/test_gpu_multiproc.py, never yet run over RCCL on 8 GPUs); replica: one "
+                         "video per GPU (weak scaling, no collective); cfg (c2 / ar_chunk): GPU pairs split the CFG halves of one video")
     ap.add_argument("--denoise-steps", type=int, default=None, help="override Euler steps per chunk (debug only: INVALID for reporting)")
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
                     help="16-bit element type of the kernels (fp32 accumulation either way, same MFMA rate): fp16 (default) = the reference's "
@@ -614,6 +618,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true")
     args = ap.parse_args()
+    if args.parallelism == "auto":
+        args.parallelism = "pairs" if (args.gpus > 1 and args.gpus % 2 == 0) else "replica"
     if args.steps is None:
         args.steps = 6 if args.workload == "stage1" else 1
 
@@ -650,7 +656,7 @@ def main():
     # parallelism: "replica" = one independent video per rank (no data-path collective);
     #              "cfg"     = ranks (2k, 2k+1) split the two CFG halves of one video, one RCCL all-gather per Euler step
     cfg_ex, n_videos, video_id = None, world, rank
-    if args.parallelism == "job":
+    if args.parallelism in ("job", "pairs"):
         args.parallelism = "replica"            # c2 / ar_chunk are single-chunk parity workloads: replicas unless --parallelism cfg
     if args.parallelism == "cfg":
         import torch.distributed as dist

@@ -242,8 +242,25 @@ class JobPlan:
             why = self.validate(world, frames_cond, min_pix)
             if why is not None:
                 self.mode, self.fallback_reason = "replica", why
+        if self.mode == "pairs" and world % 2:
+            self.mode, self.fallback_reason = "replica", f"CFG pairs need an even number of GPUs, got {world}"
         if self.mode == "replica":
             self.n_videos, self.video_id = world, rank
+            return
+        if self.mode == "pairs":
+            # world / 2 independent videos, each on a CFG pair: ranks (2k, 2k+1) evaluate the unconditional | conditional half of every network
+            # call of video k and all-gather the 3.7 MB network output once per Euler step; the pair also splits the decode's frame groups.
+            # No sequence parallelism, no all-to-all: the only collectives are a 2-rank all-gather and a 2-rank broadcast.
+            pairs = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
+            self.cfg_exchange = CfgPairExchange(pairs[rank // 2])
+            self.decode_group = pairs[rank // 2]
+            self.n_videos, self.video_id = world // 2, rank // 2
+            if preflight:
+                why = self._preflight()
+                if why is not None:
+                    self.mode, self.fallback_reason = "replica", why
+                    self.cfg_exchange = self.decode_group = None
+                    self.n_videos, self.video_id = world, rank
             return
         pairs = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]           # every rank creates every group, same order
         halves = [dist.new_group(list(range(h, world, 2))) for h in (0, 1)] if world > 2 else [None, None]
@@ -289,8 +306,9 @@ class JobPlan:
                 sums = sp.allreduce_sums(torch.ones((1, 32, 2), dtype=torch.float64, device=dev))
                 assert float(sums[0, 0, 0]) == sp.size, "fp64 all-reduce"
             t = torch.full((3, 5), float(self.rank), device=dev)
-            broadcast(t, src=0, group=self.decode_group)
-            assert float(t[0, 0]) == 0.0, "broadcast"
+            src = dist.get_global_rank(self.decode_group, 0)
+            broadcast(t, src=src, group=self.decode_group)
+            assert float(t[0, 0]) == float(src), "broadcast"
             if dev.type == "cuda":
                 torch.cuda.synchronize()
         except Exception as e:                      # noqa: BLE001 -- whatever the backend throws, the job must still produce a number
@@ -312,7 +330,12 @@ class JobPlan:
 
     @property
     def scaling(self):
-        return "weak" if (self.mode == "replica" and self.world > 1) else "strong"
+        # replicas: work grows with the GPUs; CFG pairs: one video on 2 GPUs is strong scaling, more pairs add videos (weak)
+        if self.world == 1:
+            return "strong"
+        if self.mode == "replica" or (self.mode == "pairs" and self.world > 2):
+            return "weak"
+        return "strong"
 
     def attach(self, wrapper, vae):
         """Give the networks their share of the plan: the StreamingWrapper runs its forward sequence-parallel over `sp`; the decoder
@@ -327,6 +350,10 @@ class JobPlan:
         if self.mode == "replica":
             why = f"; fell back from the one-job plan: {self.fallback_reason}" if self.fallback_reason else ""
             return f"replica-per-gpu x{self.world} (independent videos, no data-path collective{why})"
+        if self.mode == "pairs":
+            return (f"{self.n_videos} independent video(s), each on a CFG pair of GPUs (ranks 2k | 2k+1 evaluate the unconditional | conditional half; "
+                    f"one RCCL all-gather of the 3.7 MB network output per Euler step; decode frame groups split inside the pair); no collective "
+                    f"between pairs")
         sp = self.sp.size if self.sp else 1
         return (f"one job over {self.world} GPUs: CFG pair (RCCL all-gather of the network output per Euler step) x frame<->pixel sequence "
                 f"parallelism of degree {sp} (RCCL all-to-all around the temporal operators, all-reduce of the 5-D GroupNorm sums), "

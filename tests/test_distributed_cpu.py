@@ -176,7 +176,19 @@ def _sp_worker(rank, world, port, out):
         one = StreamingSVD(None, dec).decode_first_stage(zz)
         dec.decode_group = vae.decode_group
         two = StreamingSVD(None, dec).decode_first_stage(zz)
-        out.put((rank, e_sp, e_sp0, e_job, torch.equal(one, two), plan.describe(), plan.scaling))
+        # (4) bench.py's DEFAULT plan: world / 2 independent videos, each on a CFG pair (no sequence parallelism); decode split inside the pair
+        wrap.sp = None
+        pplan = parallel.JobPlan(world, rank, "pairs")
+        pvae = _Vae()
+        pplan.attach(wrap, pvae)
+        zp = EulerEDMSampler(num_steps=2, num_frames=T, cfg_exchange=pplan.cfg_exchange)(wrap, sin["noise"].clone(), sin["c"], sin["uc"], batch_size=2,
+                                                                                        num_video_frames=T, ctrl_frames=inp["ctrl_frames"])
+        e_pairs = ((zp - z_ref).abs().max() / z_ref.abs().max()).item()
+        dec.decode_group = pvae.decode_group
+        three = StreamingSVD(None, dec).decode_first_stage(zz)
+        pairs_ok = (pplan.mode == "pairs" and pplan.n_videos == world // 2 and pplan.video_id == rank // 2 and torch.equal(one, three)
+                    and pplan.scaling == ("strong" if world == 2 else "weak") and wrap.sp is None)
+        out.put((rank, e_sp, e_sp0, e_job, torch.equal(one, two), plan.describe(), plan.scaling, e_pairs, pairs_ok))
     finally:
         dist.destroy_process_group()
 
@@ -196,7 +208,8 @@ def test_sequence_parallel_forward_equals_single_process(world):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, e_sp, e_sp0, e_job, dec_ok, desc, scaling in res:
+    for rank, e_sp, e_sp0, e_job, dec_ok, desc, scaling, e_pairs, pairs_ok in res:
+        assert e_pairs < 2e-4 and pairs_ok, (rank, e_pairs, pairs_ok)
         assert e_sp < 2e-4 and e_sp0 < 2e-4, (rank, e_sp, e_sp0)          # fp32 on both sides: summation order only
         assert e_job < 2e-4, (rank, e_job)
         assert dec_ok and scaling == "strong"

@@ -95,6 +95,18 @@ def _worker(rank, world, port, out):
         two = StreamingSVD(wrap, vae).decode_first_stage(zdec, clamp=True)
         res["decode_identical"] = bool(torch.equal(one, two))
         res["desc"], res["scaling"] = plan.describe(), plan.scaling
+        # (3) bench.py's DEFAULT plan for --gpus N: N / 2 independent videos, each on a CFG pair; decode split inside the pair
+        wrap.sp = None
+        wrap.reset_caches()
+        pplan = parallel.JobPlan(world, rank, "pairs", frames_cond=TC)
+        assert pplan.mode == "pairs", pplan.fallback_reason
+        pvae = AutoencodingEngineDecoder(dec)
+        pplan.attach(wrap, pvae)
+        zp = EulerEDMSampler(num_steps=2, num_frames=T, cfg_exchange=pplan.cfg_exchange)(wrap, noise.clone(), sc, suc, batch_size=2,
+                                                                                        num_video_frames=T, ctrl_frames=win["ctrl_frames"])
+        res["pairs_bit_identical"] = bool(torch.equal(zp, z_ref))          # the CFG split is exact: same bits as one process
+        res["pairs_decode_identical"] = bool(torch.equal(StreamingSVD(wrap, pvae).decode_first_stage(zdec, clamp=True), one))
+        res["pairs_videos"] = (pplan.n_videos, pplan.video_id)
         torch.cuda.synchronize()
         out.put(res)
     finally:
@@ -121,5 +133,6 @@ def test_job_plan_on_hip_kernels_multi_process(world):
         assert d["e_sp"] < 2e-3 and d["e_sp0"] < 2e-3, d
         assert d["e_job"] < 4e-3, d
         assert d["decode_identical"] and d["scaling"] == "strong"
+        assert d["pairs_bit_identical"] and d["pairs_decode_identical"] and d["pairs_videos"] == (world // 2, d["rank"] // 2), d
     # every rank of a run ends with the same state (the collectives deliver identical bits everywhere)
     assert len({round(d["e_job"], 12) for d in res}) == 1
