@@ -356,8 +356,9 @@ def build_stage1(args, world, device):
     wrapper, vae = build_models("stage1", device)
     plan.attach(wrapper, vae)
     sampler = EulerEDMSampler(num_steps=args.denoise_steps or 30, num_frames=T_FRAMES, min_scale=1.5, max_scale=3.0,
-                              discretization=AlignYourSteps(), cfg_exchange=plan.cfg_exchange)
+                              discretization=AlignYourSteps(), cfg_exchange=plan.cfg_exchange, use_graph=args.graph)
     model = StreamingSVD(wrapper, vae, sampler)
+    model.use_graph = args.graph
     if args.denoise_steps:
         model.initial_num_steps = args.denoise_steps
     c, uc, _, _ = synthetic_inputs(device, 33 + plan.video_id)
@@ -615,6 +616,8 @@ def main():
                          "own autocast precision (config.yaml:8), the one the parity tests assert north_star's tolerance in; bf16 selectable")
     ap.add_argument("--residual-stream", default=None, choices=["fp32", "16"],
                     help="residual stream of the UNet / ControlNet between kernels (default: the package default, streamingt2v_amd.ops.STREAM_F32)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the per-step network evaluation from a hipGraph captured at the second Euler step of every chunk (sampling.EulerEDMSampler(use_graph=True))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true")
     args = ap.parse_args()

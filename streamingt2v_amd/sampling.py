@@ -78,10 +78,17 @@ class LinearPredictionGuider:
 class EulerEDMSampler:
     """30 Euler steps on the AYS schedule with per-frame linear guidance (config.yaml:139-158)."""
 
-    def __init__(self, num_steps=30, num_frames=25, min_scale=1.5, max_scale=3.0, discretization=None, cfg_exchange=None):
+    def __init__(self, num_steps=30, num_frames=25, min_scale=1.5, max_scale=3.0, discretization=None, cfg_exchange=None, use_graph=False):
         """cfg_exchange: optional streamingt2v_amd.parallel.CfgPairExchange -- this rank then evaluates only ITS half
-        of the CFG batch per step and all-gathers the raw network outputs with its partner (exact 2-way split)."""
+        of the CFG batch per step and all-gathers the raw network outputs with its partner (exact 2-way split).
+        use_graph: capture the network evaluation of a chunk's SECOND step in a hipGraph (torch.cuda.CUDAGraph around the libsvdhip launches: they
+        go to torch's current stream, which is the capture stream) and replay it for the remaining steps -- ~1 000 Python launcher calls per
+        forward (26 us of host time each, profiles/r03_host_probe.txt) become one graph launch.  The shapes, the conditioning tensors and every
+        cached constant are fixed within a chunk; the per-step scalars live in device vectors (StreamingWrapper.step_scalars).  Not used when the
+        wrapper runs sequence-parallel (collectives inside the forward)."""
         self.cfg_exchange = cfg_exchange
+        self.use_graph = use_graph
+        self._graph_pool = None
         self.num_steps = num_steps
         self.discretization = discretization or AlignYourSteps()
         self.guider = LinearPredictionGuider(max_scale=max_scale, num_frames=num_frames, min_scale=min_scale)
@@ -111,12 +118,36 @@ class EulerEDMSampler:
             half = (uc, cond)[ex.half]
             c2 = {k: half[k].float().contiguous() for k in ("vector", "crossattn", "concat")}
             model_kwargs = dict(model_kwargs, batch_size=1)
+        graph = graph_net = None
+        graphable = (self.use_graph and x.is_cuda and getattr(wrapper, "sp", None) is None and hasattr(wrapper, "forward_fused_static")
+                     and set(model_kwargs) <= {"batch_size", "num_video_frames", "ctrl_frames", "image_only_indicator"})
         for i in range(len(sig) - 1):
             s = float(np.float32(sig[i]))                     # s_in * sigmas[i] is fp32 in the reference
             s_next = float(np.float32(sig[i + 1]))
             _, _, c_in, c_noise = self.scaling(s)
-            net = wrapper.forward_fused(x, c_in, c_noise, c2, **model_kwargs)   # [2T*pix, 4] fp32 tokens
+            if graph is not None:
+                scale, tvec = wrapper.step_scalars(x, model_kwargs["batch_size"])
+                scale.fill_(c_in)
+                tvec.fill_(c_noise)
+                graph.replay()
+                net = graph_net
+            else:
+                net = wrapper.forward_fused(x, c_in, c_noise, c2, **model_kwargs)   # [2T*pix, 4] fp32 tokens
+                if graphable and i == 0 and len(sig) > 3:
+                    # step 0 ran eagerly (it also fills the per-chunk caches and the kernels' one-time attributes); capture the forward once
+                    # now -- nothing executes during capture -- and replay it from step 1 on
+                    graph, graph_net = self._capture(wrapper, x, c2, model_kwargs)
             if ex is not None:
                 net = ex.gather(net)                          # (uncond | cond) from the two ranks of the pair
             ops.edm_euler_step(x, net, g, s, s_next)
         return x
+
+    def _capture(self, wrapper, x, c2, model_kwargs):
+        kw = {k: model_kwargs[k] for k in ("batch_size", "num_video_frames") if k in model_kwargs}
+        kw["ctrl_frames"] = model_kwargs.get("ctrl_frames")
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()      # one private pool for all chunks' graphs (a chunk's graph replaces the last)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            net = wrapper.forward_fused_static(x, c2, **kw)
+        return g, net

@@ -87,7 +87,9 @@ class StreamingSVD:
         T = self.sampler.guider.num_frames
         num_steps = num_steps or self.initial_num_steps
         sampler = EulerEDMSampler(num_steps=num_steps, num_frames=T, min_scale=min_scale, max_scale=max_scale,
-                                  discretization=EDMDiscretization(), cfg_exchange=self.sampler.cfg_exchange)
+                                  discretization=EDMDiscretization(), cfg_exchange=self.sampler.cfg_exchange,
+                                  use_graph=getattr(self.sampler, "use_graph", False))
+        sampler._graph_pool = getattr(self.sampler, "_graph_pool", None)
         x = noise.clone().float().contiguous()
         z = sampler(self.inference_model, x, c, uc, batch_size=2, num_video_frames=T, ctrl_frames=None)
         return self.decode_first_stage(z, clamp=True)

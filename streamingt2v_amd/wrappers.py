@@ -108,7 +108,16 @@ class StreamingWrapper:
         """x [T,4,h,w] fp32 (UNscaled sampler state); c2: cond dict with batch_size*T rows (batch_size = 2: CFG-doubled
         (uncond | cond); batch_size = 1: ONE CFG half, used by the CFG-pair split over two ranks).  Returns the raw network
         output tokens [batch_size*T*h*w, 4] fp32, i.e. network(cat([x]*batch_size) * c_in, c_noise, c2)."""
-        T, _, H, W = x.shape
+        scale, tvec = self.step_scalars(x, batch_size)
+        scale.fill_(c_in)
+        tvec.fill_(c_noise)
+        return self.forward_fused_static(x, c2, batch_size=batch_size, num_video_frames=num_video_frames, ctrl_frames=ctrl_frames)
+
+    def step_scalars(self, x, batch_size):
+        """The two per-step scalars of a fused forward (c_in, c_noise; denoiser_scaling.py:51-59) as DEVICE vectors [batch_size * T]: the only
+        inputs of `forward_fused_static` that change between the Euler steps of a chunk besides x itself -- which is what makes one captured
+        hipGraph of the forward replayable for every step (sampling.EulerEDMSampler(use_graph=True))."""
+        T = x.shape[0]
         key = (x.device, T, batch_size)
         aux = getattr(self, "_aux", {}).get(key)
         if aux is None:
@@ -116,9 +125,13 @@ class StreamingWrapper:
                    torch.empty((batch_size * T,), dtype=torch.float32, device=x.device))
             self._aux = getattr(self, "_aux", {})
             self._aux[key] = aux
-        scale, tvec = aux
-        scale.fill_(c_in)
-        tvec.fill_(c_noise)
+        return aux
+
+    def forward_fused_static(self, x, c2, *, batch_size, num_video_frames, ctrl_frames=None):
+        """forward_fused with c_in / c_noise read from the `step_scalars` vectors: no host value enters a kernel argument, no allocation
+        outlives the call except the returned tensor, nothing synchronises -- capturable in a hipGraph."""
+        T, _, H, W = x.shape
+        scale, tvec = self.step_scalars(x, batch_size)
         x2 = torch.cat([x] * batch_size, 0) if batch_size > 1 else x
         x_tok = ops.nchw_to_tokens(x2, c2["concat"], scale, 32)          # (x * c_in | concat) -> 8 ch, padded to 32
         return self._run(x_tok, tvec, c2["crossattn"], c2["vector"], batch_size, num_video_frames, H, W, ctrl_frames)

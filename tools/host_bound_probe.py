@@ -32,6 +32,24 @@ with torch.no_grad():
         print(f"AR chunk: host returned after {t1 - t0:.3f} s, GPU finished after {t2 - t0:.3f} s; {calls['n']} libsvdhip calls "
               f"({(t1 - t0) / max(calls['n'], 1) * 1e6:.1f} us of host time per call)", flush=True)
 
+# ---- part 1b: the same AR chunk with the per-step forward replayed from a hipGraph (captured at step 1 of the chunk) ---------------------------
+gs = EulerEDMSampler(num_steps=30, num_frames=25, min_scale=1.5, max_scale=3.0, discretization=AlignYourSteps(), use_graph=True)
+gmodel = StreamingSVD(wrapper, vae, gs)
+with torch.no_grad():
+    ref = model._generate_conditional_output(c, uc, ctrl, noise)
+    got = gmodel._generate_conditional_output(c, uc, ctrl, noise); torch.cuda.synchronize()
+    print(f"hipGraph replay of the per-step forward: frames bit-identical to the eager chunk: {bool(torch.equal(ref, got))}", flush=True)
+    for rep in range(2):
+        calls["n"] = 0
+        t0 = time.perf_counter()
+        gmodel._generate_conditional_output(c, uc, ctrl, noise)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"AR chunk, graphed steps: host returned after {t1 - t0:.3f} s, GPU finished after {t2 - t0:.3f} s; {calls['n']} libsvdhip calls from Python "
+              f"(step 0 eager + one capture + decode)", flush=True)
+del gmodel, gs
+
 # ---- part 2: host cost of a launch WITHOUT queue back-pressure -------------------------------------------------------------------------
 # The shipped architecture on a 16x16 latent (kernels of a few microseconds: the GPU drains the queue faster than Python fills it), so the
 # time until forward() returns is pure host work: Python layer logic + ctypes marshalling + hipLaunchKernel.  This is the number that bounds
@@ -66,3 +84,26 @@ n = calls["n"] / 5
 print(f"shipped architecture on a {fc['h']}x{fc['w']} latent ({2 * T} frames): {n:.0f} libsvdhip calls per forward; host returns after {(t1 - t0) / 5 * 1e3:.1f} ms "
       f"({(t1 - t0) / 5 / n * 1e6:.1f} us of host time per call), GPU done after {(t2 - t0) / 5 * 1e3:.1f} ms  -> a forward costs >= {(t1 - t0) / 5 * 1e3:.0f} ms of "
       f"host time whatever the GPU share of a rank is")
+
+# ---- part 3: host cost of a REPLAYED forward (hipGraph) on the same small case ------------------------------------------------------------------
+with torch.no_grad():
+    x = inp["x"][:T].contiguous()
+    c2 = {k: cc[k].float().contiguous() for k in ("vector", "crossattn", "concat")}
+    scale, tvec = wrap.step_scalars(x, 2)
+    scale.fill_(0.5); tvec.fill_(0.1)
+    kwg = dict(batch_size=2, num_video_frames=T, ctrl_frames=inp["ctrl_frames"])
+    ref = wrap.forward_fused_static(x, c2, **kwg)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = wrap.forward_fused_static(x, c2, **kwg)
+    g.replay(); torch.cuda.synchronize()
+    same = bool(torch.equal(out, ref))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g.replay()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+print(f"same forward replayed from a hipGraph (bit-identical: {same}): host returns after {(t1 - t0) / 5 * 1e3:.2f} ms per forward, GPU done after "
+      f"{(t2 - t0) / 5 * 1e3:.1f} ms  -> the host cost of a step no longer depends on the number of kernels")
