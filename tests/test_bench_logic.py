@@ -117,3 +117,16 @@ def test_job_plan_is_validated_up_front():
     assert "divisible" in JobPlan.validate(10)                        # sp = 5 does not divide the 144 pixels of the lowest level
     p = JobPlan(world=16, rank=3, mode="job")                         # no process group needed: the plan falls back before creating any
     assert p.mode == "replica" and p.scaling == "weak" and p.n_videos == 16 and p.video_id == 3 and "fell back" in p.describe()
+
+
+def test_full_pipeline_frame_arithmetic_matches_the_reference_functions():
+    """bench.py --workload full counts the frames the job DELIVERS: with randomized blending the reference keeps whole windows only
+    (i2v_enhance_interface.py:88-113) and vfi_process interpolates every remaining pair and repeats the last frame (:30-52)."""
+    from streamingt2v_amd.pipeline import enhance_windows, num_autoregressive_generations
+    assert num_autoregressive_generations(100) == 5                       # 100 stage-1 frames = chunk 0 + 5 AR chunks
+    starts, kept = enhance_windows(100, 38, 12)
+    assert starts == [0, 26, 52] and kept == 90                            # 3 windows of 38 with overlap 12; 10 frames dropped
+    video_len = 200
+    n_in = min(kept, video_len // 2 + 1)                                   # vfi_process: video[:video_len // 2 + 1]
+    n_out = 2 * (n_in - 1) + 1 + (1 if video_len % 2 == 0 else 0)
+    assert n_out == 180
