@@ -166,6 +166,12 @@ int svd_groupnorm_stats(const void* X, int64_t ldx, int32_t frames, int32_t pix,
 int svd_groupnorm_apply(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix,
                         int32_t channels, int32_t groups, int32_t frames_per_stat, const float* stats,
                         const float* gamma, const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream);
+/* One-call form (ABI v7): statistics pass + apply pass.  When a (stat batch, group) pair has <= 64 partial sums (every per-frame norm of
+ * the UNet / ControlNet: util.py:274-276 GroupNorm32 of the 2-D ResBlocks, attention.py:132-135) the apply pass reduces them itself and no
+ * finalize kernel runs (`stats` untouched); otherwise identical to svd_groupnorm_stats followed by svd_groupnorm_apply. */
+int svd_groupnorm(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix, int32_t channels,
+                  int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats, const float* gamma,
+                  const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream);
 /* Sequence-parallel form of the 5-D statistics (time_stack GroupNorms models/diffusion/video_model.py:75-80 and the CAM merger's
  * norm models/cam/conditioning.py:57-59 pool over ALL frames and pixels of a batch element): when the frames / pixels of a batch element
  * are sharded over the ranks of a process group, every rank reduces ITS rows to sums[frames/frames_per_stat][groups][2] = (sum, sum of
@@ -191,6 +197,31 @@ int svd_layernorm(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t 
  * channel padding to cpad, scaled per frame by scale[f] (NULL = 1).  (wrappers.py:33 concat + Denoiser c_in) */
 int svd_nchw_to_tokens(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
                        svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream);
+/* ---- extended-precision rim (ABI v7, csrc/precision.hip) -------------------------------------------------------
+ * SPLIT-3 operands: x_hi = rn16(x), x_lo = rn16(x - x_hi); a row of C values is stored as [hi(C) | lo(C) | hi(C)] and multiplied by
+ * weights packed [W_hi | W_hi | W_lo] (per tap for the convolution views): svd_gemm then accumulates A_hi W_hi + A_lo W_hi + A_hi W_lo
+ * in fp32 -- ~22-bit operands on the unchanged MFMA kernels.  Used where oracle/ablate_precision_sites.py shows the 16-bit error
+ * budget concentrates at negligible FLOPs: ControlNetConditioningEmbedding (models/control/controlnet.py:51-121, once per chunk) and
+ * the stem convolutions input_blocks.0.0 (models/diffusion/video_model.py:569, models/control/controlnet.py:524).
+ * svd_nchw_to_tokens_x3: svd_nchw_to_tokens with split-3 output rows [frames*pix, 3*cpad]. */
+int svd_nchw_to_tokens_x3(const float* X0, int32_t c0, const float* X1, int32_t c1, const float* scale,
+                          svd_bf16* Y, int32_t cpad, int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream);
+/* fp32 rows [rows, channels <= 512] -> split-3 rows [rows, 3*channels]; flags: per-row LayerNorm over the channels (gamma, beta, eps;
+ * the embedding's per-pixel nn.LayerNorm, controlnet.py:108-114) and / or SiLU first, both in fp32. */
+enum { SVD_SPLIT3_LAYERNORM = 1, SVD_SPLIT3_SILU = 2 };
+int svd_rows_split3(const float* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels, const float* gamma,
+                    const float* beta, float eps, int32_t flags, int32_t dtype, svd_stream_t stream);
+/* Y = X + B with B fp32 (Merger addition of the fp32 image-condition embedding, controlnet.py:41-42); X / Y 16 bit, or fp32 with
+ * dtype | SVD_DTYPE_IN_F32. */
+int svd_add_rows_bf32(const void* X, int64_t ldx, const float* B, int64_t ldb, void* Y, int64_t ldy, int64_t rows, int32_t channels,
+                      int32_t dtype, svd_stream_t stream);
+/* The UNet's head in ONE fp32 kernel: Y[m][0..cout) = conv3x3( SiLU( GroupNorm(X) ) ) + bias, cout <= 4, zero padding
+ * (out.0 GroupNorm32 + SiLU + out.2 conv, models/diffusion/video_model.py:493-494,617).  X: channels-last rows of `frames` frames of
+ * H x W pixels (16 bit, or fp32 with dtype | SVD_DTYPE_IN_F32); stats: (mean, rstd) per (frame / frames_per_stat, group) as written by
+ * svd_groupnorm_stats; Wt: fp32 [9 taps (ky, kx)][channels][4] (cout padded to 4); Y fp32 rows with leading dimension ldy. */
+int svd_head_gn_silu_conv3x3(const void* X, int64_t ldx, int32_t frames, int32_t H, int32_t W, int32_t channels, int32_t groups,
+                             int32_t frames_per_stat, const float* stats, const float* gamma, const float* beta, const float* Wt,
+                             const float* bias, float* Y, int64_t ldy, int32_t cout, int32_t dtype, svd_stream_t stream);
 /* channels-last (x_dtype: BF16 | F16 | F32; first c channels of rows with stride ld) -> NCHW fp32 */
 int svd_tokens_to_nchw(const void* X, int32_t x_dtype, int64_t ldx, float* Y, int32_t c, int32_t frames,
                        int32_t pix, svd_stream_t stream);

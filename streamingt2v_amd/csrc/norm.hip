@@ -1,5 +1,6 @@
 // GroupNorm(32) (+SiLU) and LayerNorm on channels-last bf16 activations -- HBM-bound kernels, fp32 statistics.
 #include "svd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -138,26 +139,57 @@ __global__ void gn_stats_from_sums_kernel(const double* __restrict__ sums, int n
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-template <class E, bool IN32>
+// FIN = the statistics are FINALIZED HERE (round 4): every workgroup reduces the frames_per_stat * nchunk partial sums of its (stat batch,
+// group) pairs itself -- at most 64 entries per group, i.e. <= 16 KB of L2-resident partials against the 100+ KB of activations the workgroup
+// moves -- instead of reading the output of a separate gn_finalize launch (15.5 k launches of 5 us per three AR chunks, round-3 kernel trace;
+// the time_stack / CAM norms, which pool 25 frames x 36 chunks, keep the finalize kernel).  Same arithmetic (double sums, fixed order).
+template <class E, bool IN32, bool FIN>
 __global__ void gn_apply_kernel(const void* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y, int64_t ldy, int pix,
                                 int channels, int groups, int frames_per_stat, int nchunk, const float* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, int silu) {
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int silu, float count, float eps) {
     const int octets = channels >> 3;
     const int R = blockDim.x / octets;
     const int o = threadIdx.x % octets, rr = threadIdx.x / octets;
-    if (rr >= R) return;
     const int f = blockIdx.y, chunk = blockIdx.x;
     const int rows_per_chunk = (pix + nchunk - 1) / nchunk;
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk; if (r1 > pix) r1 = pix;
     const int cpg = channels / groups;
     const int sb = f / frames_per_stat;
+    __shared__ float sst[64];
+    if constexpr (FIN) {
+        // `stats` is the PARTIAL buffer here: entry e = fr * nchunk + c of (sb, g) at ((sb * n + e) * groups + g) * 2.  Two threads per group
+        // (even / odd entries), combined in a fixed order.
+        const int t = threadIdx.x;
+        if (t < 2 * groups) {
+            const int g = t >> 1, half = t & 1;
+            const int n = frames_per_stat * nchunk;
+            const float* base = stats + ((int64_t)sb * n * groups + g) * 2;
+            double a = 0.0, b = 0.0;
+            for (int e = half; e < n; e += 2) {
+                const float2 v = *(const float2*)(base + (int64_t)e * groups * 2);
+                a += v.x; b += v.y;
+            }
+            a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
+            if (!half) {
+                const double mean = a / (double)count;
+                double var = b / (double)count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                sst[2 * g] = (float)mean;
+                sst[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+            }
+        }
+        __syncthreads();
+    }
+    if (rr >= R) return;
     float ca[8], cb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = o * 8 + i;
         const int g = c / cpg;
-        const float mean = stats[((int64_t)sb * groups + g) * 2], rstd = stats[((int64_t)sb * groups + g) * 2 + 1];
+        float mean, rstd;
+        if constexpr (FIN) { mean = sst[2 * g]; rstd = sst[2 * g + 1]; }
+        else { mean = stats[((int64_t)sb * groups + g) * 2]; rstd = stats[((int64_t)sb * groups + g) * 2 + 1]; }
         const float ga = gamma[c] * rstd;
         ca[i] = ga; cb[i] = beta[c] - mean * ga;
     }
@@ -278,6 +310,100 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     }
 }
 
+// LayerNorm, PACKED form (round 4): LPR lanes per token row, 64 / LPR rows per wave, up to 5 16-byte vectors per lane (octet = sub + LPR * k,
+// so the LPR lanes of a row read LPR x 16 contiguous bytes per instruction).  The one-row-per-wave kernel above leaves 24 of 64 lanes idle at
+// C = 320 (40 octets) and has ONE 16-byte load per lane in flight per row: 3.1-3.4 TB/s at C = 320 / 640 against 5.0 TB/s for its own fp32-input
+// form (profiles/r03_norm_bandwidth.txt).  Here every lane carries data at C = 320 / 640 / 1280 (LPR = 8 / 16 / 32, 5 vectors each) and a wave
+// has 5 x 1 KiB of loads in flight.  Same arithmetic as above (two passes over the registers, fp32); the reductions run inside the LPR lanes.
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int LPR, class E, bool IN32>
+__global__ __launch_bounds__(256) void layernorm_packed_kernel(const void* __restrict__ X, int64_t ldx, svd_bf16* __restrict__ Y,
+                                                               int64_t ldy, int64_t rows, int channels, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               const float* __restrict__ addvec, int addvec_ld, int rows_per_vec,
+                                                               void* __restrict__ Xsum, int64_t ldxsum, int silu) {
+    constexpr int MAXV = 5;
+    constexpr int RW = 64 / LPR;                       // rows per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, rsel = lane / LPR;
+    const int octets = channels >> 3;
+    const float invc = 1.f / (float)channels;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row0 = wave_id * RW; row0 < rows; row0 += nwaves * RW) {
+        const bool live = row0 + rsel < rows;
+        const int64_t row = live ? row0 + rsel : rows - 1;                // tail: recompute the last row, stores masked
+        const void* xr = row_ptr<IN32>(X, row, ldx);
+        const float* av = addvec ? addvec + (row / rows_per_vec) * addvec_ld : nullptr;
+        float v[MAXV][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int o = sub + LPR * k;
+            if (o < octets) load8<E, IN32>(xr, o * 8, v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int o = sub + LPR * k;
+            if (o < octets) {
+                if (av) {
+                    const float4 a0 = *(const float4*)(av + o * 8), a1 = *(const float4*)(av + o * 8 + 4);
+                    v[k][0] += a0.x; v[k][1] += a0.y; v[k][2] += a0.z; v[k][3] += a0.w;
+                    v[k][4] += a1.x; v[k][5] += a1.y; v[k][6] += a1.z; v[k][7] += a1.w;
+                    if (Xsum && live) {
+                        if constexpr (IN32) {          // the sum continues the fp32 residual stream
+                            float* xs = (float*)Xsum + row * ldxsum + o * 8;
+                            *(float4*)xs = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                            *(float4*)(xs + 4) = make_float4(v[k][4], v[k][5], v[k][6], v[k][7]);
+                        } else {
+                            uint4 w;
+                            w.x = E::pack(v[k][0], v[k][1]); w.y = E::pack(v[k][2], v[k][3]);
+                            w.z = E::pack(v[k][4], v[k][5]); w.w = E::pack(v[k][6], v[k][7]);
+                            *(uint4*)((svd_bf16*)Xsum + row * ldxsum + o * 8) = w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += v[k][i];
+            }
+        }
+        const float mean = group_sum<LPR>(sum) * invc;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int o = sub + LPR * k;
+            if (o < octets) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(group_sum<LPR>(sq) * invc + eps);
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int o = sub + LPR * k;
+            if (o < octets && live) {
+                const float4 g0 = *(const float4*)(gamma + o * 8), g1 = *(const float4*)(gamma + o * 8 + 4);
+                const float4 b0 = *(const float4*)(beta + o * 8), b1 = *(const float4*)(beta + o * 8 + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    y[i] = (v[k][i] - mean) * rstd * gg[i] + bb[i];
+                    if (silu) y[i] = silu_f(y[i]);
+                }
+                uint4 w;
+                w.x = E::pack(y[0], y[1]); w.y = E::pack(y[2], y[3]);
+                w.z = E::pack(y[4], y[5]); w.w = E::pack(y[6], y[7]);
+                *(uint4*)(Y + row * ldy + o * 8) = w;
+            }
+        }
+    }
+}
+
 inline int gn_block(int channels) {
     const int octets = channels >> 3;
     int R = 256 / octets; if (R < 1) R = 1;
@@ -353,9 +479,37 @@ extern "C" int svd_groupnorm_apply(const void* X, int64_t ldx, svd_bf16* Y, int6
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return SVD_EINVAL;
     const int nchunk = gn_nchunk(frames, pix);
     const int bs = gn_block(channels);
-    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_apply_kernel<E, IN32>), dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy,
-                                              pix, channels, groups, frames_per_stat, nchunk, stats, gamma, beta, silu));
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_apply_kernel<E, IN32, false>), dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy,
+                                              pix, channels, groups, frames_per_stat, nchunk, stats, gamma, beta, silu, 0.f, 0.f));
     SVD_CHECK_LAUNCH("gn_apply");
+    return SVD_OK;
+}
+
+// GroupNorm (+SiLU) in one call (round 4): statistics pass + apply pass; the apply pass finalizes the statistics itself when a (stat batch,
+// group) pair has <= 64 partial sums (every per-frame norm of the UNet / ControlNet), else gn_finalize runs in between as before.
+// Replaces torch.nn.GroupNorm / GroupNorm32 (util.py:274-276) like the two-call form; `stats` is only written on the finalize path.
+extern "C" int svd_groupnorm(const void* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int32_t frames, int32_t pix, int32_t channels,
+                             int32_t groups, int32_t frames_per_stat, float eps, float* partial, float* stats, const float* gamma,
+                             const float* beta, int32_t silu, int32_t dtype, svd_stream_t stream) {
+    if (!X || !Y || !partial || !stats || !gamma || !beta || frames <= 0 || pix <= 0 || channels <= 0) return SVD_EINVAL;
+    if (groups <= 0 || groups > 32 || channels % groups || channels % 8 || ldx % 8 || ldy % 8 || channels > 8192) return SVD_EINVAL;
+    if (frames_per_stat <= 0 || frames % frames_per_stat || frames > 65535) return SVD_EINVAL;
+    if (((uintptr_t)X | (uintptr_t)Y) & 15) return SVD_EINVAL;
+    const int nchunk = gn_nchunk(frames, pix);
+    const int bs = gn_block(channels);
+    static const bool fuse = []{ const char* e = getenv("SVD_GN_FUSED_FINALIZE"); return !(e && e[0] == '0'); }();
+    if (!fuse || frames_per_stat * nchunk > 64 || bs < 2 * groups) {
+        int rc = svd_groupnorm_stats(X, ldx, frames, pix, channels, groups, frames_per_stat, eps, partial, stats, dtype, stream);
+        if (rc != SVD_OK) return rc;
+        return svd_groupnorm_apply(X, ldx, Y, ldy, frames, pix, channels, groups, frames_per_stat, stats, gamma, beta, silu, dtype, stream);
+    }
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_stats_partial_kernel<E, IN32>), dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
+                                              (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
+    SVD_CHECK_LAUNCH("gn_stats_partial");
+    const float count = (float)frames_per_stat * (float)pix * (float)(channels / groups);
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_apply_kernel<E, IN32, true>), dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy,
+                                              pix, channels, groups, frames_per_stat, nchunk, partial, gamma, beta, silu, count, eps));
+    SVD_CHECK_LAUNCH("gn_apply_fin");
     return SVD_OK;
 }
 
@@ -367,9 +521,29 @@ extern "C" int svd_layernorm(const void* X, int64_t ldx, svd_bf16* Y, int64_t ld
     if (addvec && (rows_per_vec <= 0 || addvec_ld % 4)) return SVD_EINVAL;
     if (Xsum && (!addvec || ldxsum % 8)) return SVD_EINVAL;
     if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)addvec | (uintptr_t)Xsum) & 15) return SVD_EINVAL;
+    const int octets = channels / 8;
+    // packed form (LPR lanes per row, <= 5 vectors per lane) for C <= 1280; SVD_LN_PACKED=0: the one-row-per-wave kernel (A/B reference)
+    static const bool packed = []{ const char* e = getenv("SVD_LN_PACKED"); return !(e && e[0] == '0'); }();
+    // (measured, gpurun r4a: C = 320 181 -> 150 us, C = 640 96 -> 81 us for the level's 295 MB; at C = 1280 the one-row-per-wave kernel already has 3
+    // vectors per lane in flight and is as fast or faster (33.2 vs 33.9 us; fp32 input 38.5 vs 43.0) -> packed form for C <= 640 only)
+    if (packed && octets <= 80) {
+        const int lpr = octets <= 20 ? 4 : octets <= 40 ? 8 : 16;
+        const int rows_per_block = 4 * (64 / lpr);
+        int64_t nb = (rows + rows_per_block - 1) / rows_per_block;          // one pass per workgroup (a capped grid left 1.76 passes per workgroup at
+        if (nb > 65535 * 8) nb = 65535 * 8;                                  // level 0: half the workgroups ran twice as long as the others)
+#define LNP_LAUNCH(L)                                                                                                                \
+    SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((layernorm_packed_kernel<L, E, IN32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, \
+                                              X, ldx, Y, ldy, rows, channels, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,            \
+                                              Xsum, ldxsum, silu))
+        if (lpr == 4) LNP_LAUNCH(4);
+        else if (lpr == 8) LNP_LAUNCH(8);
+        else LNP_LAUNCH(16);
+#undef LNP_LAUNCH
+        SVD_CHECK_LAUNCH("layernorm_packed");
+        return SVD_OK;
+    }
     int64_t blocks = (rows + 7) / 8;                      // 4 waves x (up to) 2 rows per workgroup pass
     if (blocks > 256 * 32) blocks = 256 * 32;
-    const int octets = channels / 8;
 #define LN_LAUNCH(MV)                                                                                                        \
     SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((layernorm_kernel<MV, E, IN32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
                                               X, ldx, Y, ldy, rows, channels, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,    \

@@ -30,14 +30,14 @@ def _lib_file():
 
 LIB_PATH = os.path.join(_HERE, _lib_file())
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
     "svd_abi_version", "svd_last_error", "svd_gemm", "svd_gemm_num_configs", "svd_gemm_config_info", "svd_gemm_pick_config", "svd_gemm_config_valid",
     "svd_attn_spatial_d64", "svd_attn_temporal_d64", "svd_softmax_rows",
-    "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_groupnorm_sums", "svd_groupnorm_stats_from_sums", "svd_layernorm",
-    "svd_nchw_to_tokens", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32", "svd_cast_rows_f32", "svd_permute_rows",
+    "svd_groupnorm_partial_elems", "svd_groupnorm_stats", "svd_groupnorm_apply", "svd_groupnorm", "svd_groupnorm_sums", "svd_groupnorm_stats_from_sums", "svd_layernorm",
+    "svd_nchw_to_tokens", "svd_nchw_to_tokens_x3", "svd_rows_split3", "svd_add_rows_bf32", "svd_head_gn_silu_conv3x3", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32", "svd_cast_rows_f32", "svd_permute_rows",
     "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
     "svd_attn_cross_d64", "svd_adaptive_avgpool_tokens", "svd_i2v_image_temporal_encoder", "svd_ddim_cfg_step", "svd_frames_to_uint8", "svd_gelu_rows",
     "svd_prelu_rows", "svd_dwconv3x3_gelu", "svd_window_attn_7x7", "svd_warp_bilinear", "svd_resize_bilinear_f32", "svd_vfi_merge", "svd_vfi_tta_average",
@@ -108,12 +108,17 @@ def _load():
     lib.svd_softmax_rows.argtypes = [vp, i64, vp, i64, i64, i32, f32, i32, vp]
     lib.svd_groupnorm_stats.argtypes = [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]
     lib.svd_groupnorm_apply.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp]
+    lib.svd_groupnorm.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, vp]
     lib.svd_groupnorm_sums.argtypes = [vp, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.svd_groupnorm_stats_from_sums.argtypes = [vp, i32, i32, C.c_double, f32, vp, vp]
     lib.svd_layernorm.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, f32, vp, i32, i32, vp, i64, i32, i32, vp]
     lib.svd_nchw_to_tokens.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.svd_tokens_to_nchw.argtypes = [vp, i32, i64, vp, i32, i32, i32, vp]
     lib.svd_concat_channels.argtypes = [vp, i64, i32, vp, i64, i32, vp, i64, i64, vp]
+    lib.svd_nchw_to_tokens_x3.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    lib.svd_rows_split3.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, f32, i32, i32, vp]
+    lib.svd_add_rows_bf32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
+    lib.svd_head_gn_silu_conv3x3.argtypes = [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     lib.svd_add_rows.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
     lib.svd_cast_f32.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.svd_cast_rows_f32.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp]

@@ -43,6 +43,43 @@ def set_stream_f32(on=True):
     STREAM_F32 = bool(on)
 
 
+# PRECISION PLAN (round 4).  oracle/ablate_precision_sites.py emulates the 16-bit execution of StreamingWrapper.forward on the CPU oracle and
+# keeps one site of the network exact at a time: the deviation from the reference's fp32 path concentrates in places that cost next to nothing --
+#   EXACT_RIM   the ControlNet's image-condition embedding (15 % of the squared error; computed once per chunk), the two stem convolutions and
+#               the UNet's head (7.5 %; GroupNorm + SiLU + conv to 4 channels) run with split-3 (~22-bit) MFMA operands / in fp32 (csrc/precision.hip);
+#   CN_STREAM_F32  the fp32 residual stream INSIDE THE CONTROLNET only (16 % of the squared error for ~1/8 of the stream's bytes: the ControlNet
+#               sees 14 of the 64 frames of a forward and only the encoder half).
+# Both are the package default; STREAM_F32 (the whole UNet's stream in fp32, +7 % job time) stays an option.
+EXACT_RIM = True
+CN_STREAM_F32 = True
+
+
+def set_precision_plan(exact_rim=None, cn_stream_f32=None):
+    """Select the round-4 precision plan (None = leave).  Like set_element_dtype: call BEFORE load_state_dict (the rim packs its own weights)."""
+    global EXACT_RIM, CN_STREAM_F32
+    if exact_rim is not None:
+        EXACT_RIM = bool(exact_rim)
+    if cn_stream_f32 is not None:
+        CN_STREAM_F32 = bool(cn_stream_f32)
+
+
+class stream_scope:
+    """with stream_scope(True): the fp32 residual stream is on for the networks evaluated inside (ControlNet.forward_tokens)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global STREAM_F32
+        self.prev = STREAM_F32
+        STREAM_F32 = self.prev or self.on
+
+    def __exit__(self, *exc):
+        global STREAM_F32
+        STREAM_F32 = self.prev
+        return False
+
+
 def set_element_dtype(dt=None):
     """Select the 16-bit element type of everything created from here on (None: back to DEFAULT_ELEM).  Call it BEFORE load_state_dict:
     packed weights keep the type they were packed in."""
@@ -296,12 +333,11 @@ def groupnorm(x, frames, pix, gamma, beta, eps, *, frames_per_stat=1, silu=False
     if worklog is not None:
         _wl("gn_stats_partial_kernel", 0.0, float(rows) * Cc * x.element_size())
         _wl("gn_apply_kernel", 0.0, float(rows) * Cc * (x.element_size() + 2))
-    check(_lib.svd_groupnorm_stats(_p(x), ld, frames, pix, Cc, groups, frames_per_stat, float(eps), _p(partial),
-                                   _p(stats), _dt_in(x), _stream()), "svd_groupnorm_stats")
     if out is None:
         out = torch.empty((rows, Cc), dtype=_odt(x), device=x.device)
-    check(_lib.svd_groupnorm_apply(_p(x), ld, _p(out), out.stride(0), frames, pix, Cc, groups, frames_per_stat,
-                                   _p(stats), _p(gamma), _p(beta), int(silu), _dt_in(x), _stream()), "svd_groupnorm_apply")
+    # one call: statistics pass + apply pass (the apply pass finalizes per-frame statistics itself: no gn_finalize launch)
+    check(_lib.svd_groupnorm(_p(x), ld, _p(out), out.stride(0), frames, pix, Cc, groups, frames_per_stat, float(eps), _p(partial),
+                             _p(stats), _p(gamma), _p(beta), int(silu), _dt_in(x), _stream()), "svd_groupnorm")
     return out
 
 
@@ -364,6 +400,61 @@ def nchw_to_tokens(x0, x1, scale, cpad):
     out = torch.empty((F_ * pix, cpad), dtype=ELEM, device=x0.device)
     check(_lib.svd_nchw_to_tokens(_p(x0), c0, _p(x1), c1, _p(scale), _p(out), cpad, F_, pix, _dt(out), _stream()),
           "svd_nchw_to_tokens")
+    return out
+
+
+def nchw_to_tokens_x3(x0, x1, scale, cpad):
+    """nchw_to_tokens with SPLIT-3 rows [F*H*W, 3*cpad] = [hi | lo | hi] (extended-precision operand of the stem convolutions)."""
+    F_, c0 = x0.shape[0], x0.shape[1]
+    pix = x0.shape[2] * x0.shape[3]
+    c1 = x1.shape[1] if x1 is not None else 0
+    assert x0.dtype == torch.float32 and x0.is_contiguous()
+    if x1 is not None:
+        assert x1.dtype == torch.float32 and x1.is_contiguous() and x1.shape[0] == F_
+    out = torch.empty((F_ * pix, 3 * cpad), dtype=ELEM, device=x0.device)
+    check(_lib.svd_nchw_to_tokens_x3(_p(x0), c0, _p(x1), c1, _p(scale), _p(out), cpad, F_, pix, _dt(out), _stream()),
+          "svd_nchw_to_tokens_x3")
+    return out
+
+
+def rows_split3(x, ln=None, eps=1e-5, silu=False):
+    """fp32 rows [rows, C <= 512] -> split-3 16-bit rows [rows, 3 C]; ln = (gamma, beta): per-row LayerNorm first, then SiLU (both fp32)."""
+    rows, ld = _rows_ld(x)
+    assert x.dtype == torch.float32
+    Cc = x.shape[1]
+    out = torch.empty((rows, 3 * Cc), dtype=ELEM, device=x.device)
+    flags = (1 if ln is not None else 0) | (2 if silu else 0)
+    g, b = ln if ln is not None else (None, None)
+    check(_lib.svd_rows_split3(_p(x), ld, _p(out), out.stride(0), rows, Cc, _p(g), _p(b), float(eps), flags, _dt(out), _stream()),
+          "svd_rows_split3")
+    return out
+
+
+def add_rows_f32b(x, b):
+    """x + b row-wise with b fp32 (x 16 bit or the fp32 stream; the sum has x's type, rounded once)."""
+    assert b.dtype == torch.float32 and b.shape == x.shape and b.stride(1) == 1
+    out = torch.empty_like(x)
+    dt = (_DT[ELEM] | _l.DTYPE_IN_F32) if x.dtype == torch.float32 else _dt(x)
+    check(_lib.svd_add_rows_bf32(_p(x), x.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1], dt, _stream()),
+          "svd_add_rows_bf32")
+    return out
+
+
+def head_gn_silu_conv3x3(x, frames, H, W, gamma, beta, eps, wt, bias, cout, groups=32):
+    """conv3x3(SiLU(GroupNorm(x))) + bias -> fp32 [frames*H*W, 4] (first `cout` columns valid), all in fp32 arithmetic: the UNet's head."""
+    rows, ld = _rows_ld(x)
+    Cc = x.shape[1]
+    pix = H * W
+    assert rows == frames * pix and wt.dtype == torch.float32 and wt.is_contiguous() and tuple(wt.shape) == (9, Cc, 4)
+    partial, stats = _gn_workspace(x.device, frames, Cc, frames, groups)
+    if worklog is not None:
+        _wl("gn_stats_partial_kernel", 0.0, float(rows) * Cc * x.element_size())
+        _wl("head_gn_silu_conv3x3_kernel", 2.0 * rows * 9 * Cc * 4, float(rows) * Cc * x.element_size() + rows * 16.0)
+    check(_lib.svd_groupnorm_stats(_p(x), ld, frames, pix, Cc, groups, 1, float(eps), _p(partial), _p(stats), _dt_in(x), _stream()),
+          "svd_groupnorm_stats")
+    out = torch.empty((rows, 4), dtype=torch.float32, device=x.device)
+    check(_lib.svd_head_gn_silu_conv3x3(_p(x), ld, frames, H, W, Cc, groups, 1, _p(stats), _p(gamma), _p(beta), _p(wt), _p(bias), _p(out), 4, cout,
+                                        _dt_in(x), _stream()), "svd_head_gn_silu_conv3x3")
     return out
 
 

@@ -66,6 +66,17 @@ def pack_geglu(w, b):
     return torch.stack([wv, wg], 1).reshape(2 * half, K), torch.stack([bv, bg], 1).reshape(2 * half)
 
 
+def pack_x3(w2d, taps):
+    """fp32 GEMM weight [N, taps * cin] (K order (tap, c)) -> the SPLIT-3 weight [N, taps * 3 * cin] in the element type: per tap
+    [W_hi | W_hi | W_lo] with W_hi = rn16(W), W_lo = rn16(W - W_hi), matching activation rows [A_hi | A_lo | A_hi] (csrc/precision.hip)."""
+    N, K = w2d.shape
+    cin = K // taps
+    w = w2d.detach().float().reshape(N, taps, cin)
+    hi = w.to(ops.ELEM)
+    lo = (w - hi.float()).to(ops.ELEM)
+    return torch.cat([hi, hi, lo], 2).reshape(N, taps * 3 * cin).contiguous()
+
+
 def pad_rows(w, n):
     if w.shape[0] >= n:
         return w
@@ -464,25 +475,37 @@ class ConditionalModel:
 class _Conv:
     """3x3 conv (stem / Downsample.op / Upsample.conv / out) as implicit GEMM."""
 
-    def __init__(self, prefix, cin, cout, stride=1, ups=0):
+    def __init__(self, prefix, cin, cout, stride=1, ups=0, x3=False):
         self.p, self.cin, self.cout, self.stride, self.ups = prefix, cin, cout, stride, ups
         self.cin_pad = cin if cin % 32 == 0 else (cin + 31) // 32 * 32
         self.cout_pad = cout if cout % 4 == 0 else (cout + 3) // 4 * 4
+        self.x3 = x3              # a rim convolution: split-3 operands when the precision plan asks for them (ops.EXACT_RIM at prepare time)
+        self.w3 = None
 
     def spec(self, s):
         s.add(self.p + "weight", self.cout, self.cin, 3, 3); s.add(self.p + "bias", self.cout)
 
     def prepare(self, sd, dev):
-        self.w = _dev_bf16(pack_conv3x3(sd[self.p + "weight"], self.cin_pad, self.cout_pad), dev)
+        wp = pack_conv3x3(sd[self.p + "weight"], self.cin_pad, self.cout_pad)
+        self.w = _dev_bf16(wp, dev)
         self.b = _dev_f32(pad_rows(sd[self.p + "bias"].detach().float(), self.cout_pad), dev)
+        self.w3 = pack_x3(wp, 9).to(dev) if (self.x3 and ops.EXACT_RIM) else None
 
     def forward(self, x, F, H, W, **kw):
+        """x: 16-bit (or fp32-stream) rows [F*H*W, cin_pad]; a rim convolution (w3) also takes SPLIT-3 rows [F*H*W, 3*cin_pad] (ops.rows_split3 /
+        ops.nchw_to_tokens_x3) or fp32 rows, which it splits itself."""
         if self.stride == 2:
             ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         elif self.ups:
             ho, wo = 2 * H, 2 * W
         else:
             ho, wo = H, W
+        if self.w3 is not None and (x.shape[1] == 3 * self.cin_pad or x.dtype == torch.float32):
+            if x.shape[1] != 3 * self.cin_pad:
+                x = ops.rows_split3(x)
+            cv = dict(cin=3 * self.cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=self.stride, ups=self.ups, frames=F)
+            return ops.gemm(x, self.w3, bias=self.b, conv=cv, **kw), ho, wo
+        assert x.shape[1] == self.cin_pad or self.w3 is None, "split-3 rows handed to a convolution prepared without the rim weights"
         cv = dict(cin=self.cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=self.stride, ups=self.ups, frames=F)
         return ops.gemm(ops.to_elem_rows(x), self.w, bias=self.b, conv=cv, **kw), ho, wo
 
@@ -536,6 +559,15 @@ class _EncoderBase:
     def eval(self):
         return self
 
+    @property
+    def stem_x3(self):
+        """True when the stem convolution was prepared with split-3 weights (ops.EXACT_RIM at load time): x_tok must then be split-3 rows."""
+        return self.input_blocks[0][0].w3 is not None
+
+    def input_tokens(self, x0, x1, scale):
+        """NCHW fp32 (x0 * scale | x1) -> the stem's input rows: [F*H*W, 32] 16 bit, or split-3 [F*H*W, 96] for a rim stem."""
+        return (ops.nchw_to_tokens_x3 if self.stem_x3 else ops.nchw_to_tokens)(x0, x1, scale, 32)
+
     def reset_caches(self):
         """Drop the per-chunk caches (context tensors, one-token cross-attention constants, the ControlNet's condition embedding): they hold
         strong references to the last chunk's `context` / control frames (~50 MB) and are keyed on tensor identity + version -- call this
@@ -552,7 +584,7 @@ class _EncoderBase:
         self.cfg, self.mc, self.emb_ch = cfg, mc, emb
         self.time_embed = _EmbedMLP("time_embed.", mc, emb, emb)
         self.label_emb = _EmbedMLP("label_emb.0.", cfg.adm_in_channels, emb, emb)
-        self.input_blocks = [[_Conv("input_blocks.0.0.", cfg.in_channels, mc)]]
+        self.input_blocks = [[_Conv("input_blocks.0.0.", cfg.in_channels, mc, x3=True)]]
         self.input_block_chans = [mc]
         ch, ds, idx = mc, 1, 1
         for level, mult in enumerate(cfg.channel_mult):
@@ -700,6 +732,14 @@ class VideoUNet(_EncoderBase):
         for m in self._modules():
             m.prepare(sd, device)
         self.ow, self.ob = _dev_f32(sd["out.0.weight"], device), _dev_f32(sd["out.0.bias"], device)
+        # the head in fp32 (ops.EXACT_RIM): out.2 weights as [tap (ky, kx)][c][4] for svd_head_gn_silu_conv3x3
+        self.head_wt = None
+        if ops.EXACT_RIM and self.out_channels <= 4 and self.mc % 32 == 0:
+            w = sd["out.2.weight"].detach().float()                                      # [cout, C, 3, 3]
+            wt = torch.zeros(3, 3, self.mc, 4, dtype=torch.float32)
+            wt[..., : self.out_channels] = w.permute(2, 3, 1, 0)
+            self.head_wt = wt.reshape(9, self.mc, 4).contiguous().to(device)
+            self.head_b = _dev_f32(pad_rows(sd["out.2.bias"].detach().float(), 4), device)
         self._pack_emb_layers()
         self.device = device
         self.prepared = True
@@ -733,8 +773,11 @@ class VideoUNet(_EncoderBase):
             assert (Hs, Ws) == (H, W)
             h = ops.concat_channels(h, skip)
             h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, **kw)
-        h = ops.groupnorm(h, F, H * W, self.ow, self.ob, 1e-5, silu=True)
-        out, _, _ = self.out_conv.forward(h, F, H, W, out_f32=True)
+        if self.head_wt is not None:        # GroupNorm + SiLU + conv to 4 channels as one fp32 kernel (precision plan; also faster than a 4-wide MFMA tile)
+            out = ops.head_gn_silu_conv3x3(h, F, H, W, self.ow, self.ob, 1e-5, self.head_wt, self.head_b, self.out_channels)
+        else:
+            h = ops.groupnorm(h, F, H * W, self.ow, self.ob, 1e-5, silu=True)
+            out, _, _ = self.out_conv.forward(h, F, H, W, out_f32=True)
         if sp is not None:
             out = sp.gather_frames(out, timesteps.numel() // T, T, H * W)
         return out
@@ -746,7 +789,7 @@ class VideoUNet(_EncoderBase):
         if image_only_indicator is not None and bool(image_only_indicator.any()):
             raise NotImplementedError("image_only_indicator != 0 (AlphaBlender 'where' branch) is unused by StreamingSVD")
         F, _, H, W = x.shape
-        x_tok = ops.nchw_to_tokens(x.float().contiguous(), None, None, 32)
+        x_tok = self.input_tokens(x.float().contiguous(), None, None)
         out = self.forward_tokens(x_tok, timesteps.float().contiguous(), context, y.float().contiguous(),
                                   num_video_frames, H, W, hs_control_input, hs_control_mid, num_conditional_frames)
         return ops.tokens_to_nchw(out, self.out_channels, F, H, W)
@@ -757,12 +800,12 @@ class ControlNetConditioningEmbedding:
 
     def __init__(self, prefix, out_ch, block_out=(32, 96, 256, 512)):
         self.p, self.out_ch, self.bo = prefix, out_ch, tuple(block_out)
-        self.conv_in = _Conv(prefix + "conv_in.", 3, block_out[0])
+        self.conv_in = _Conv(prefix + "conv_in.", 3, block_out[0], x3=True)
         self.blocks = []
         for i in range(len(block_out) - 1):
-            self.blocks.append(_Conv(prefix + f"blocks.{2 * i}.", block_out[i], block_out[i]))
-            self.blocks.append(_Conv(prefix + f"blocks.{2 * i + 1}.", block_out[i], block_out[i + 1], stride=2))
-        self.conv_out = _Conv(prefix + "conv_out.", block_out[-1], out_ch)
+            self.blocks.append(_Conv(prefix + f"blocks.{2 * i}.", block_out[i], block_out[i], x3=True))
+            self.blocks.append(_Conv(prefix + f"blocks.{2 * i + 1}.", block_out[i], block_out[i + 1], stride=2, x3=True))
+        self.conv_out = _Conv(prefix + "conv_out.", block_out[-1], out_ch, x3=True)
 
     def spec(self, s):
         self.conv_in.spec(s)
@@ -783,6 +826,17 @@ class ControlNetConditioningEmbedding:
     def forward(self, cond_nchw):
         """cond [Fc, 3, 8H, 8W] fp32 in [-1,1] -> tokens [Fc*H*W, out_ch]."""
         Fc, _, H, W = cond_nchw.shape
+        if self.conv_in.w3 is not None and all(c <= 512 for c in self.bo):
+            # precision plan (ops.EXACT_RIM): the whole embedding with split-3 operands, fp32 between the layers, LayerNorm + SiLU in fp32.
+            # It runs once per chunk (ControlNet.embed_condition) and carries 15 % of the forward's squared 16-bit error when run in 16 bit.
+            s3 = ops.nchw_to_tokens_x3(cond_nchw.float().contiguous(), None, None, 32)
+            h, H, W = self.conv_in.forward(s3, Fc, H, W, silu=True, out_f32=True)
+            s3 = ops.rows_split3(h)
+            for b, (nw, nb) in zip(self.blocks, self.norms):
+                h, H, W = b.forward(s3, Fc, H, W, out_f32=True)
+                s3 = ops.rows_split3(h, ln=(nw, nb), silu=True)
+            h, H, W = self.conv_out.forward(s3, Fc, H, W, out_f32=True)
+            return h, H, W                       # fp32 rows: added to the stem output by svd_add_rows_bf32
         h = ops.nchw_to_tokens(cond_nchw.float().contiguous(), None, None, 32)
         h, H, W = self.conv_in.forward(h, Fc, H, W, silu=True)
         for b, (nw, nb) in zip(self.blocks, self.norms):
@@ -848,27 +902,29 @@ class ControlNet(_EncoderBase):
 
     def forward_tokens(self, x_tok, timesteps, controlnet_cond, context, y, T, H, W, sp=None):
         """With `sp`: x_tok and controlnet_cond hold this rank's share of the B*T conditioning frames; the returned features do too."""
-        emb_silu, emb_full, ctx, tctx, F = self._local_conditioning(timesteps, context, y, T, sp)
-        assert x_tok.shape[0] == F * H * W
-        cond = self.embed_condition(controlnet_cond)
-        hs = []
-        h = x_tok
-        for i, blk in enumerate(self.input_blocks):
-            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, sp=sp, emb_full=emb_full)
-            if i == 0:
-                if cond.shape[0] != h.shape[0]:
-                    raise ValueError(f"controlnet_cond embeds to {cond.shape[0]} tokens but the latent batch has {h.shape[0]}: the control "
-                                     f"frames must be {controlnet_cond.shape[0]} x 3 x {8 * H} x {8 * W} pixels (8x the latent, controlnet.py:75-102)")
-                h = ops.add_rows(h, cond)          # Merger 'addition', frame_expansion none (controlnet.py:23-48)
-            hs.append(h)
-        h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W, sp=sp, emb_full=emb_full)
-        return hs, h
+        with ops.stream_scope(ops.CN_STREAM_F32):       # precision plan: the fp32 residual stream inside the ControlNet (its features leave as fp32 rows)
+            emb_silu, emb_full, ctx, tctx, F = self._local_conditioning(timesteps, context, y, T, sp)
+            assert x_tok.shape[0] == F * H * W
+            cond = self.embed_condition(controlnet_cond)
+            hs = []
+            h = x_tok
+            for i, blk in enumerate(self.input_blocks):
+                h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, sp=sp, emb_full=emb_full)
+                if i == 0:
+                    if cond.shape[0] != h.shape[0]:
+                        raise ValueError(f"controlnet_cond embeds to {cond.shape[0]} tokens but the latent batch has {h.shape[0]}: the control "
+                                         f"frames must be {controlnet_cond.shape[0]} x 3 x {8 * H} x {8 * W} pixels (8x the latent, controlnet.py:75-102)")
+                    # Merger 'addition', frame_expansion none (controlnet.py:23-48); the rim embedding arrives in fp32
+                    h = ops.add_rows_f32b(h, cond) if cond.dtype == torch.float32 else ops.add_rows(h, cond)
+                hs.append(h)
+            h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W, sp=sp, emb_full=emb_full)
+            return hs, h
 
     def forward(self, x, timesteps, controlnet_cond, context=None, y=None, time_context=None, num_video_frames=None,
                 num_video_frames_conditional=None, image_only_indicator=None):
         """Reference signature (controlnet.py:496-507); returns token tensors (consumed by VideoUNet's CAM mergers)."""
         assert num_video_frames == num_video_frames_conditional
         F, _, H, W = x.shape
-        x_tok = ops.nchw_to_tokens(x.float().contiguous(), None, None, 32)
+        x_tok = self.input_tokens(x.float().contiguous(), None, None)
         return self.forward_tokens(x_tok, timesteps.float().contiguous(), controlnet_cond, context,
                                    y.float().contiguous(), num_video_frames, H, W)

@@ -54,6 +54,7 @@ class StreamingWrapper:
             # "(2 B) F ..." in the reference (B = 1 video, CFG batch 2); one copy per batch element here so that a rank
             # holding a single CFG half (parallel.CfgPairExchange) repeats once
             cond = self._cond_cached(ctrl_frames, batch_size)
+            assert self.controlnet.stem_x3 == self.diffusion_model.stem_x3, "UNet and ControlNet were loaded under different precision plans (ops.EXACT_RIM)"
             if sp is not None:
                 assert sp.size <= Tc, "sequence parallelism shards the Tc conditioning frames of the ControlNet: degree <= Tc"
                 x_ctrl = sp.take_frames(x_ctrl, batch_size, Tc, pix)
@@ -94,8 +95,7 @@ class StreamingWrapper:
         ctrl_frames = kwargs.get("ctrl_frames")
         F, _, H, W = x.shape
         concat = c.get("concat")
-        x_tok = ops.nchw_to_tokens(x.float().contiguous(), concat.float().contiguous() if concat is not None else None,
-                                   None, 32)
+        x_tok = self.diffusion_model.input_tokens(x.float().contiguous(), concat.float().contiguous() if concat is not None else None, None)
         out = self._run(x_tok, t.float().contiguous(), c["crossattn"].float(), c["vector"].float().contiguous(),
                         batch_size, T, H, W, ctrl_frames)
         return ops.tokens_to_nchw(out, self.diffusion_model.out_channels, F, H, W)
@@ -133,5 +133,5 @@ class StreamingWrapper:
         T, _, H, W = x.shape
         scale, tvec = self.step_scalars(x, batch_size)
         x2 = torch.cat([x] * batch_size, 0) if batch_size > 1 else x
-        x_tok = ops.nchw_to_tokens(x2, c2["concat"], scale, 32)          # (x * c_in | concat) -> 8 ch, padded to 32
+        x_tok = self.diffusion_model.input_tokens(x2, c2["concat"], scale)          # (x * c_in | concat) -> 8 ch, padded to 32 (split-3 for a rim stem)
         return self._run(x_tok, tvec, c2["crossattn"], c2["vector"], batch_size, num_video_frames, H, W, ctrl_frames)

@@ -165,6 +165,53 @@ def nchw_to_tokens(x0, x1, scale, cpad):
     return out.reshape(F_ * pix, cpad).to(ops.ELEM)
 
 
+def _split3(v):
+    """fp32 rows -> [hi | lo | hi] in the element type (csrc/precision.hip); with fp32 'elements' lo is exactly zero."""
+    from streamingt2v_amd import ops
+    hi = v.to(ops.ELEM)
+    lo = (v - hi.float()).to(ops.ELEM)
+    return torch.cat([hi, lo, hi], 1)
+
+
+def nchw_to_tokens_x3(x0, x1, scale, cpad):
+    return _split3(_tokens_f32(x0, x1, scale, cpad))
+
+
+def _tokens_f32(x0, x1, scale, cpad):
+    F_, c0 = x0.shape[0], x0.shape[1]
+    pix = x0.shape[2] * x0.shape[3]
+    out = torch.zeros((F_, pix, cpad), dtype=torch.float32, device=x0.device)
+    a = x0.float() * (scale[:, None, None, None] if scale is not None else 1.0)
+    out[..., :c0] = a.flatten(2).transpose(1, 2)
+    if x1 is not None:
+        out[..., c0:c0 + x1.shape[1]] = x1.float().flatten(2).transpose(1, 2)
+    return out.reshape(F_ * pix, cpad)
+
+
+def rows_split3(x, ln=None, eps=1e-5, silu=False):
+    v = x.float()
+    if ln is not None:
+        v = F.layer_norm(v, (x.shape[1],), ln[0], ln[1], eps)
+    if silu:
+        v = F.silu(v)
+    return _split3(v)
+
+
+def add_rows_f32b(x, b):
+    return (x.float() + b.float()).to(x.dtype)
+
+
+def head_gn_silu_conv3x3(x, frames, H, W, gamma, beta, eps, wt, bias, cout, groups=32):
+    C = x.shape[1]
+    v = x.float().reshape(frames, H * W, C).transpose(1, 2).reshape(frames, C, H, W)
+    v = F.silu(F.group_norm(v, groups, gamma, beta, eps))
+    w = wt.reshape(3, 3, C, 4).permute(3, 2, 0, 1)                        # [tap(ky, kx)][c][co] -> [co, c, ky, kx]
+    b4 = torch.zeros(4, dtype=torch.float32, device=x.device)
+    b4[:cout] = bias[:cout]
+    y = F.conv2d(v, w, b4, padding=1)
+    return y.permute(0, 2, 3, 1).reshape(frames * H * W, 4).contiguous()
+
+
 def tokens_to_nchw(x, c, frames, h, w):
     return x.float()[:, :c].reshape(frames, h * w, c).transpose(1, 2).reshape(frames, c, h, w).contiguous()
 
@@ -234,7 +281,8 @@ def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
 
 
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
-         "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3")
+         "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3",
+         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3")
 
 
 def install(monkeypatch=None):

@@ -42,7 +42,7 @@ def check(name, got, ref, atol, rtol):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 26])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 320, 320), (77, 960, 64), (4096, 640, 1280)])
 def test_gemm_plain(ops, cfg, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
@@ -81,12 +81,12 @@ def test_gemm_epilogues(ops):
     check("gemm silu", out, F.silu(a.float() @ w.float().t() + bias), 2e-2, 1e-2)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 8, 17, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("cfg", [1, 2, 8, 17, 19, 20, 21, 22, 23, 24, 26])
 @pytest.mark.parametrize("K", [32, 128, 704])
 def test_gemm_many_tiles_per_workgroup(ops, cfg, K, M=33000):
     """More tiles than resident workgroups: exercises the persistent loop (tile prologue requested before the previous tile's epilogue,
     the static / dynamic vmcnt waits for 2-, 3- and 4-stage rings) and the aux-slot ring; K shorter / longer than the ring."""
-    if K % 64 and cfg not in (17, 19, 23):
+    if K % 64 and cfg not in (17, 19, 23, 24, 26):
         pytest.skip("config needs K % 64 == 0")
     N, rpv = 512, 1000
     a, w = rnd(M, K, seed=30), rnd(N, K, scale=K ** -0.5, seed=31)
@@ -103,7 +103,7 @@ def test_gemm_many_tiles_per_workgroup(ops, cfg, K, M=33000):
     check(f"many tiles cfg{cfg} K{K} f32", out, mm, 2e-3, 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 9, 10, 11, 12, 17, 18, 19, 20])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 9, 10, 11, 12, 17, 18, 19, 20, 23, 26])
 def test_gemm_geglu(ops, cfg):
     from streamingt2v_amd.video_model import pack_geglu
     M, C = 300, 320
@@ -134,7 +134,7 @@ def test_gemm_conv3x3(ops, stride, ups, cin, cout, H, W):
     check(f"conv3x3 s{stride} u{ups} {cin}->{cout}", out, ref.permute(0, 2, 3, 1).reshape(-1, cout), 3e-2, 1e-2)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 8, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("cfg", [1, 2, 8, 19, 20, 21, 22, 23, 24, 26])
 def test_gemm_implicit_views_many_tiles(ops, cfg):
     """conv3x3 / temporal implicit GEMMs with more tiles than resident workgroups, per tile configuration
     (persistent loop across tiles) + residual + per-frame vector."""
@@ -250,7 +250,7 @@ def test_groupnorm(ops, Fr, pix, C, fps, silu):
     check(f"groupnorm C{C} fps{fps}", out, ref.transpose(1, 2).reshape(Fr * pix, C), 2e-2, 1e-2)
 
 
-@pytest.mark.parametrize("C", [32, 96, 320, 640, 1280])
+@pytest.mark.parametrize("C", [32, 96, 256, 320, 512, 640, 1024, 1280, 2048])
 def test_layernorm(ops, C):
     rows, rpv = 1000, 250
     x = rnd(rows, C, seed=33)
@@ -314,3 +314,78 @@ def test_ae_time_mix3(ops):
     x5 = x[:, :3].view(1, Fr, h * w, 3).permute(0, 3, 1, 2)[..., None]          # b c t p 1
     ref = F.conv3d(x5, wt[..., None, None], b, padding=(1, 0, 0))[0, ..., 0].permute(1, 0, 2).reshape(Fr, 3, h, w)
     check("ae time mix + clamp", out, ref.clamp(-1, 1), 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ extended-precision rim (csrc/precision.hip)
+def _join3(s3, C):
+    """split-3 rows [hi | lo | hi] -> the fp32 values they represent."""
+    return s3[:, :C].float() + s3[:, C:2 * C].float()
+
+
+@pytest.mark.parametrize("C", [32, 96, 256, 320, 512])
+def test_rows_split3(ops, C):
+    rows = 777
+    x = rnd(rows, C, seed=50, dtype=torch.float32) * 3
+    eps16 = 2.0 ** -8 if BF16 == torch.bfloat16 else 2.0 ** -11
+    s3 = ops.rows_split3(x)
+    assert torch.equal(s3[:, :C], s3[:, 2 * C:]) and torch.equal(s3[:, :C], x.to(BF16))
+    err = (_join3(s3, C) - x).abs().max().item()
+    print(f"[rows_split3 C{C}] max |hi + lo - x| = {err:.3e} (one 16-bit rounding would be ~{3 * 4 * eps16:.1e})")
+    assert err <= 16 * eps16 * eps16 * 4 + 1e-7          # lo resolves the residual to its own 16-bit rounding (+ fp16 subnormal floor)
+    g, b = rnd(C, seed=51, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=52, dtype=torch.float32) * 0.1
+    s3 = ops.rows_split3(x, ln=(g, b), eps=1e-5, silu=True)
+    ref = F.silu(F.layer_norm(x, (C,), g, b, 1e-5))
+    err = (_join3(s3, C) - ref).abs().max().item()
+    print(f"[rows_split3 C{C} LN + SiLU] max abs err {err:.3e}")
+    assert err <= 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,stride,H,W", [(3, 32, 1, 24, 40), (32, 96, 2, 24, 40), (96, 96, 1, 12, 20), (256, 512, 2, 12, 20), (8, 320, 1, 9, 16)])
+def test_x3_convolution_matches_fp32(ops, cin, cout, stride, H, W):
+    from streamingt2v_amd.video_model import _Conv
+    Fr = 3
+    prev = ops.EXACT_RIM
+    ops.set_precision_plan(exact_rim=True)
+    try:
+        conv = _Conv("c.", cin, cout, stride=stride, x3=True)
+        g = torch.Generator(); g.manual_seed(cin * 7 + cout)
+        sd = {"c.weight": torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5, "c.bias": torch.randn(cout, generator=g) * 0.1}
+        conv.prepare(sd, "cuda")
+        x = torch.randn(Fr, cin, H, W, generator=g).cuda()
+        ref = F.conv2d(x.double(), sd["c.weight"].double().cuda(), sd["c.bias"].double().cuda(), stride=stride, padding=1).float()
+        refm = ref.permute(0, 2, 3, 1).reshape(-1, cout)
+        s3 = ops.nchw_to_tokens_x3(x, None, None, conv.cin_pad)
+        out, ho, wo = conv.forward(s3, Fr, H, W, out_f32=True)
+        e3 = ((out[:, :cout] - refm).pow(2).mean().sqrt() / refm.pow(2).mean().sqrt()).item()
+        out16, _, _ = conv.forward(ops.nchw_to_tokens(x, None, None, conv.cin_pad), Fr, H, W, out_f32=True)
+        e1 = ((out16[:, :cout] - refm).pow(2).mean().sqrt() / refm.pow(2).mean().sqrt()).item()
+        print(f"[x3 conv {cin}->{cout} s{stride}] relative L2 vs fp64: split-3 {e3:.2e}, plain 16-bit operands {e1:.2e}")
+        assert e3 < (2e-5 if BF16 == torch.bfloat16 else 2e-6) and e3 < e1 / 50
+        # fp32 rows in -> the convolution splits them itself
+        if cin % 32 == 0:
+            xr = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous()
+            out2, _, _ = conv.forward(xr, Fr, H, W, out_f32=True)
+            assert torch.equal(out2, out)
+    finally:
+        ops.set_precision_plan(exact_rim=prev)
+
+
+def test_add_rows_f32b_and_head(ops):
+    a, b = rnd(300, 320, seed=60), rnd(300, 320, seed=61, dtype=torch.float32)
+    eps16 = 2.0 ** -8 if BF16 == torch.bfloat16 else 2.0 ** -11
+    check("add_rows_f32b 16-bit x", ops.add_rows_f32b(a, b), a.float() + b, 1e-6, eps16)
+    a32 = a.float() * 1.37
+    assert torch.equal(ops.add_rows_f32b(a32, b), a32 + b)
+    for Fr, H, W, C, cout in ((3, 9, 16, 320, 4), (2, 17, 37, 64, 4), (1, 8, 32, 32, 3)):
+        x = (rnd(Fr * H * W, C, seed=62).float() * 1.5 + 0.3).to(BF16)
+        g, be = rnd(C, seed=63, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=64, dtype=torch.float32) * 0.1
+        w = rnd(cout, C, 3, 3, seed=65, dtype=torch.float32) * (9 * C) ** -0.5
+        bias = rnd(4, seed=66, dtype=torch.float32) * 0.1
+        wt = torch.zeros(3, 3, C, 4, device="cuda"); wt[..., :cout] = w.permute(2, 3, 1, 0)
+        for xin in (x, x.float()):
+            out = ops.head_gn_silu_conv3x3(xin, Fr, H, W, g, be, 1e-5, wt.reshape(9, C, 4).contiguous(), bias, cout)
+            v = xin.float().reshape(Fr, H * W, C).transpose(1, 2).reshape(Fr, C, H, W)
+            ref = F.conv2d(F.silu(F.group_norm(v, 32, g, be, 1e-5)), w, bias[:cout], padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+            err = (out[:, :cout] - ref).abs().max().item()
+            print(f"[head GN+SiLU+conv3x3 {Fr}x{H}x{W}x{C}->{cout}, input {xin.dtype}] max abs err {err:.3e} (ref absmax {ref.abs().max().item():.2f})")
+            assert err < 2e-5 * max(1.0, ref.abs().max().item())

@@ -30,7 +30,7 @@ def frame_errors(out, ref):
     return dict(abs_max=e.max().item(), abs_mean=e.mean().item(), rel_max=(e / r).max().item(), ref_rms=r.mean().item(), corr=corr)
 
 
-def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=False):
+def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=False, plan=None):
     """stream_f32: None = the package default (ops.STREAM_F32), True / False = fp32 / 16-bit residual stream.  timing: also time the forward
     (3 runs after the parity run, device-synchronised) -> res['ms']."""
     from oracle.cases import FULLSIZE_CASE as c, fullsize_inputs
@@ -43,6 +43,9 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
     prev_stream = ops.STREAM_F32
     if stream_f32 is not None:
         ops.set_stream_f32(stream_f32)
+    prev_plan = (ops.EXACT_RIM, ops.CN_STREAM_F32)
+    if plan is not None:              # (exact_rim, cn_stream_f32): the round-4 precision plan (None = the package default)
+        ops.set_precision_plan(*plan)
     gold = torch.load(os.path.join(GOLD, "wrapper_fullsize.pt"))
     cfg = UNetConfig()
     unet, cn = VideoUNet(cfg), ControlNet(cfg)
@@ -60,6 +63,7 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
     torch.cuda.synchronize()
     res = frame_errors(out, gold["out"])
     res["stream_f32"] = ops.STREAM_F32
+    res["plan"] = (ops.EXACT_RIM, ops.CN_STREAM_F32)
     if timing:
         import time
         t0 = time.perf_counter()
@@ -69,6 +73,7 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
         torch.cuda.synchronize()
         res["ms"] = (time.perf_counter() - t0) / 3 * 1e3
     ops.set_stream_f32(prev_stream)
+    ops.set_precision_plan(*prev_plan)
     del unet, cn, wrap
     torch.cuda.empty_cache()
     return res
@@ -101,7 +106,9 @@ def main():
     ap.add_argument("--which", default="both")
     ap.add_argument("--stream", default="default", choices=["default", "fp32", "16", "both"], help="residual stream of the wrapper: fp32 / 16 bit / both")
     ap.add_argument("--timing", action="store_true")
+    ap.add_argument("--plans", default="default", help="'default' or 'sweep': every (exact rim, fp32 stream inside the ControlNet) combination of the round-4 precision plan")
     a = ap.parse_args()
+    plans = [None] if a.plans == "default" else [(False, False), (True, False), (False, True), (True, True)]
     sds = {}
     for name in ("fp16", "bf16"):
         if a.dtype not in ("both", name):
@@ -111,9 +118,10 @@ def main():
             print(f"[full-size VideoDecoder 2 frames @576x1024 vs reference, {name}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | "
                   f"rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | corr {r['corr']:.7f}", flush=True)
         if a.which in ("both", "wrapper"):
-            for st in {"default": [None], "fp32": [True], "16": [False], "both": [True, False]}[a.stream]:
-                r = wrapper_fullsize(name, sds=sds, stream_f32=st, timing=a.timing)
-                print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, {name}, residual stream {'fp32' if r['stream_f32'] else '16 bit'}] "
+            for st, plan in [(st, pl) for st in {"default": [None], "fp32": [True], "16": [False], "both": [True, False]}[a.stream] for pl in plans]:
+                r = wrapper_fullsize(name, sds=sds, stream_f32=st, timing=a.timing, plan=plan)
+                print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, {name}, residual stream {'fp32' if r['stream_f32'] else '16 bit'}, "
+                      f"exact rim {'on' if r['plan'][0] else 'off'}, ControlNet stream {'fp32' if r['plan'][1] else '16 bit'}] "
                       f"per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | "
                       f"corr {r['corr']:.7f}" + (f" | forward {r['ms']:.1f} ms" if "ms" in r else ""), flush=True)
 

@@ -61,7 +61,12 @@ class Tuner:
 
 
 def main():
+    import argparse
     import bench
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="'ar16': the 16-bit-stream AR forward + decode only (A/B runs of kernel variants)")
+    ap.add_argument("--out", default="", help="write the table here instead of streamingt2v_amd/gemm_tiles.json")
+    a = ap.parse_args()
     dev = "cuda:0"
     torch.cuda.set_device(0)
     tuner = Tuner()
@@ -69,7 +74,8 @@ def main():
     ops._tile_table = {}
     t0 = time.time()
     # both residual-stream forms of the UNet / ControlNet: their producers are different kernels (fp32 stream: `_o1` signatures)
-    for workload, stream in (("ar_chunk", True), ("c2", True), ("ar_chunk", False), ("c2", False)):
+    plans = (("ar_chunk", True), ("c2", True), ("ar_chunk", False), ("c2", False)) if a.only != "ar16" else (("ar_chunk", False),)
+    for workload, stream in plans:
         ops.set_stream_f32(stream)
         wrapper, vae = bench.build_models(workload, dev)
         from streamingt2v_amd.sampling import EulerEDMSampler
@@ -83,21 +89,22 @@ def main():
         del wrapper, vae, model
         torch.cuda.empty_cache()
     ops.set_stream_f32(True)
-    # enhancement stage: one I2VGen-XL UNet forward of a 38-frame window (CFG batch 2) at latent 90x160
-    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
-    from streamingt2v_amd.params import init_by_name
-    unet = I2VGenXLUNet(I2VConfig())
-    unet.load_state_dict(init_by_name(unet.spec(), seed=5, device=dev), device=dev)
-    g = torch.Generator(device=dev); g.manual_seed(1)
-    rn = lambda *sh: torch.randn(*sh, generator=g, device=dev)
-    with torch.no_grad():
-        unet(rn(2, 4, 38, 90, 160), 500, fps=torch.tensor([16, 16]), image_latents=rn(2, 4, 38, 90, 160), image_embeddings=rn(2, 1024),
-             encoder_hidden_states=rn(2, 77, 1024))
-    torch.cuda.synchronize()
-    print(f"enhance: {len(tuner.table)} signatures after {time.time() - t0:.0f}s", flush=True)
-    del unet
-    torch.cuda.empty_cache()
-    out = os.path.join(ROOT, "streamingt2v_amd", "gemm_tiles.json")
+    if a.only != "ar16":
+        # enhancement stage: one I2VGen-XL UNet forward of a 38-frame window (CFG batch 2) at latent 90x160
+        from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+        from streamingt2v_amd.params import init_by_name
+        unet = I2VGenXLUNet(I2VConfig())
+        unet.load_state_dict(init_by_name(unet.spec(), seed=5, device=dev), device=dev)
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        rn = lambda *sh: torch.randn(*sh, generator=g, device=dev)
+        with torch.no_grad():
+            unet(rn(2, 4, 38, 90, 160), 500, fps=torch.tensor([16, 16]), image_latents=rn(2, 4, 38, 90, 160), image_embeddings=rn(2, 1024),
+                 encoder_hidden_states=rn(2, 77, 1024))
+        torch.cuda.synchronize()
+        print(f"enhance: {len(tuner.table)} signatures after {time.time() - t0:.0f}s", flush=True)
+        del unet
+        torch.cuda.empty_cache()
+    out = a.out or os.path.join(ROOT, "streamingt2v_amd", "gemm_tiles.json")
     gain = sum(v["heuristic_ms"] - v["ms"] for v in tuner.table.values() if v["heuristic_ms"] == v["heuristic_ms"])
     with open(out, "w") as f:
         json.dump({"device": torch.cuda.get_device_name(0), "note": "best tile config per GEMM signature, tools/tune_gemm.py",
@@ -108,7 +115,7 @@ def main():
     print(f"GEMM time of the two tuned forwards + decode: {tot:.1f} ms; top signatures (calls x ms):")
     for k, v in rank[:45]:
         print(f"  {v['calls'] * v['ms']:8.2f} ms  {v['calls']:4d} x {v['ms']:7.3f}  cfg{v['cfg']:<3d} {v['tflops']:6.0f} TF  {k}")
-    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+    if not a.out and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
         import shutil
         shutil.copy(out, os.path.join(ROOT, "gpurun_out", "gemm_tiles.json"))
 
