@@ -125,6 +125,13 @@ def roofline_from_trace(trace):
                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
 
 
+def precision_plan():
+    """The round-4 precision plan the networks were loaded under (streamingt2v_amd.ops) -- part of every line's config."""
+    from streamingt2v_amd import ops
+    return {"element": str(ops.ELEM).replace("torch.", ""), "exact_rim": bool(ops.EXACT_RIM), "controlnet_stream_fp32": bool(ops.CN_STREAM_F32),
+            "unet_stream_fp32_min_channels": int(ops.STREAM_F32_MIN_CH), "unet_stream_fp32_everywhere": bool(ops.STREAM_F32)}
+
+
 def build_models(workload, device):
     from streamingt2v_amd.params import init_by_name
     from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VideoDecoder
@@ -188,6 +195,29 @@ def cpu_baseline(workload):
     fwd_c2 = t_unet * (2 * T_FRAMES) / (2 * T)                    # 50 frames
     fwd_ar = fwd_c2 * 181.96 / 159.9
     dec_chunk = T_FRAMES * t_dec
+    if workload == "full":
+        # + the enhancement stage: one I2VGen-XL UNet forward of the CPU oracle (full architecture, 1.42 B parameters) on CFG 2 x 2 frames at the
+        # 90x160 latent, extrapolated over frames (x 19 for a 38-frame window), 29 DDIM steps, 3 blending windows + the 3-frame key-frame pre-pass
+        # counted as 3/38 of a window; VAE encode / decode and EMA-VFI are not counted (they would make the baseline slower still).
+        from oracle import i2vgen_oracle as IO
+        from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+        with torch.no_grad():
+            sd = init_by_name(I2VGenXLUNet(I2VConfig()).spec(), seed=5)
+            Fe, he, we = 2, 90, 160
+            xs = torch.randn(2, 4, Fe, he, we, generator=g)
+            t0 = time.time()
+            IO.unet(sd, xs, torch.tensor(500), torch.tensor([38, 38]), torch.randn(2, 4, Fe, he, we, generator=g), torch.randn(2, 1024, generator=g),
+                    torch.randn(2, 77, 1024, generator=g))
+            t_enh = time.time() - t0
+            del sd
+        win_fwd = t_enh * 38 / Fe
+        enh_s = 29 * win_fwd * (3 + 3 / 38)
+        stage1_s = (25 * fwd_c2 + dec_chunk) + 5 * (30 * fwd_ar + dec_chunk)
+        return {"value": 180 / (stage1_s + enh_s), "unit": "frames/s", "cores": cores, "kind": "port",
+                "sample": f"stage 1: oracle VideoUNet forward, CFG 2 x {T} frames @ {h}x{w} latent: {t_unet:.1f} s; VideoDecoder 1 frame @ 576x1024: {t_dec:.1f} s "
+                          f"=> {stage1_s:.0f} s per 100-frame stage 1; enhancement: oracle I2VGenXLUNet forward, CFG 2 x {Fe} frames @ {he}x{we} latent: {t_enh:.1f} s; "
+                          f"x19 over frames => {win_fwd:.0f} s per 38-frame window forward, x 29 DDIM steps x (3 windows + key-frame pre-pass) => {enh_s:.0f} s; "
+                          f"VAE encode / decode and EMA-VFI not counted; 180 final frames per job"}
     if workload == "c2":
         chunk_s, frames, what = 25 * fwd_c2 + dec_chunk, T_FRAMES, "25-step chunk without ControlNet"
     elif workload == "ar_chunk":
@@ -209,16 +239,19 @@ def run_enhance(args, rank, world, device):
     from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
     from streamingt2v_amd.params import init_by_name
     chunk, H, W, cd = 38, 90, 160, 1024
-    # N = 1: one window, no overlap.  N > 1: ONE video of N blending windows (overlap 12, BASELINE configs[3]/[4]); every DDIM step
-    # each rank denoises its window and the window outputs are all-gathered over RCCL inside the timed loop (blend_step_sharded).
+    # N = 1: one window, no overlap (the per-window number of rounds 2 / 3).  N > 1: the SHIPPED job -- one 100-frame video = 3 blending windows of
+    # 38 frames, overlap 12 (i2v_enhance_interface.py:92-118), 90 frames kept -- strong-scaled: every DDIM step its 3 x 2 (window, CFG half)
+    # units go round-robin over the ranks and ONE all-gather of the units' predictions (8.75 MB each) closes the step
+    # (blending.blend_step_units_sharded); 6 units keep 6 of 8 GPUs busy (whole windows: 3 of 8).
+    n_win = 3 if world > 1 else 1
     overlap = 12 if world > 1 else 0
-    n_frames = world * chunk - (world - 1) * overlap
+    n_frames = n_win * chunk - (n_win - 1) * overlap
     unet = I2VGenXLUNet(I2VConfig())
     unet.load_state_dict(init_by_name(unet.spec(), seed=5, device=device), device=device)
     g = torch.Generator(device=device); g.manual_seed(33)            # identical on every rank: all ranks hold the same video
     rn = lambda *s: torch.randn(*s, generator=g, device=device)
     conds = []
-    for _ in range(world):
+    for _ in range(n_win):
         il, emb, text = rn(1, 4, chunk, H, W) * 0.7, rn(1, cd), rn(1, 77, cd)
         conds.append(dict(fps=torch.tensor([38, 38]), image_latents=torch.cat([il, il]),
                           image_embeddings=torch.cat([torch.zeros_like(emb), emb]), text=torch.cat([torch.zeros_like(text), text])))
@@ -256,10 +289,12 @@ def run_enhance(args, rank, world, device):
         print(json.dumps({
             "metric": "enhanced frames/sec (720x1280)", "value": round(args.steps * n_frames / dt, 4), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype.replace("fp16", "f16"), "data": "synthetic",
-            "config": {"workload": "I2VGen-XL enhancement (SDEdit): one 38-frame window @ latent 90x160, CFG 9 (batch 2x38), %d DDIM steps" % n_steps,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": args.dtype.replace("fp16", "f16"), "data": "synthetic",
+            "config": {"workload": ("I2VGen-XL enhancement (SDEdit): %d blending window(s) of 38 frames @ latent 90x160, overlap %d, CFG 9 (batch 2x38 per window), "
+                                    "%d DDIM steps" % (n_win, overlap, n_steps)),
                        "frames_per_step": n_frames, "denoise_steps": n_steps, "latent": [H, W],
-                       "parallelism": (f"blending windows sharded over {world} GPUs, one all-gather of window outputs per DDIM step" if world > 1 else "single window"),
+                       "parallelism": (f"{2 * n_win} (window, CFG half) units round-robin over {world} GPUs, one all-gather of the units' predictions per DDIM step"
+                                       if world > 1 else "single window"),
                        "weights": "seeded random, reference architecture (1.42 B parameters)"},
             "roofline": roof, "cpu_baseline": None}))
     if world > 1:
@@ -436,7 +471,8 @@ def run_stage1(args, rank, world, device):
                        "chunks_timed": [len(per_type[0]), len(per_type[1])], "timed_region_starts_at": "chunk 0 (video boundary)",
                        "frames_kept_per_chunk": list(Stage1Stream.KEPT), "frames_in_timed_steps": kept, "kept_frames_over_time": round(kept_rate, 4),
                        "latent": [LAT_H, LAT_W], "denoise_steps": [args.denoise_steps or 25, args.denoise_steps or 30],
-                       "parallelism": plan.describe(), "weights": "seeded random, reference architecture (1.59 B + 0.67 B + 64 M parameters)"},
+                       "parallelism": plan.describe(), "precision_plan": precision_plan(),
+                       "weights": "seeded random, reference architecture (1.59 B + 0.67 B + 64 M parameters)"},
             "roofline": roof, "cpu_baseline": cpu}))
     if world > 1:
         import torch.distributed as dist
@@ -516,6 +552,27 @@ def run_full(args, rank, world, device):
     # (:30-52) = 180 final frames.  value counts the frames the job actually delivers.
     n_final = out.shape[0]
     assert n_final == 2 * n_enh and out.shape[1:] == (720, 1280, 3) and str(out.dtype) == "uint8", (out.shape, out.dtype, n_enh)
+    # roofline of the job's dominant kernel: ONE more job with HIP events around every GEMM / MFMA-attention launch of all three stages (the timed
+    # region above is untraced); the GEMM family is one kernel template across stage 1, the enhancer, both VAEs and EMA-VFI.
+    roof = None
+    if not args.no_trace and world == 1:
+        from streamingt2v_amd import ops
+        trace = LaunchTrace()
+        ops.trace = trace
+        try:
+            one()
+            torch.cuda.synchronize()
+            ops.trace = None
+            roof = roofline_from_trace(trace)
+        except Exception as e:      # the timed measurement must not be lost to the trace pass
+            ops.trace = None
+            roof = {"error": repr(e)}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        try:
+            cpu = cpu_baseline("full")
+        except Exception as e:
+            cpu = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"FAILED: {e!r}"}
     if rank == 0:
         print(json.dumps({
             "metric": "final frames/sec (200-frame job, 720x1280 output)", "value": round(plan.n_videos * args.steps * n_final / dt, 4), "unit": "frames/s",
@@ -526,10 +583,14 @@ def run_full(args, rank, world, device):
                                    "+ EMA-VFI to 200 frames" % len(pipe_timesteps(pipe)),
                        "seconds_per_job": {k: round(v / args.steps, 2) for k, v in stage_s.items()}, "frames_after_enhancement": int(n_enh),
                        "final_frames_per_job": int(n_final),
-                       "parallelism": plan.describe() + ("; blending windows and VFI frame pairs sharded over all ranks" if pipe.group is not None else ""),
+                       "parallelism": {"stage1": plan.describe(),
+                                       "enhance": ("6 (window, CFG half) units + the key-frame pre-pass's 2 over the ranks of the video's group, one all-gather per DDIM step"
+                                                   if pipe.group is not None else "single GPU"),
+                                       "vfi": ("frame pairs sharded over the ranks of the video's group" if pipe.group is not None else "single GPU")},
+                       "precision_plan": precision_plan(),
                        "weights": "seeded random, reference architectures (StreamingSVD 2.3 B, I2VGen-XL 1.42 B, AutoencoderKL, CLIP ViT-H/14 image tower, EMA-VFI 65.7 M); "
                                   "CLIP text tower replaced by fixed random prompt embeddings"},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": roof, "cpu_baseline": cpu}))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -615,7 +676,11 @@ def main():
                     help="16-bit element type of the kernels (fp32 accumulation either way, same MFMA rate): fp16 (default) = the reference's "
                          "own autocast precision (config.yaml:8), the one the parity tests assert north_star's tolerance in; bf16 selectable")
     ap.add_argument("--residual-stream", default=None, choices=["fp32", "16"],
-                    help="residual stream of the UNet / ControlNet between kernels (default: the package default, streamingt2v_amd.ops.STREAM_F32)")
+                    help="residual stream of the UNet / ControlNet between kernels.  Default: the package's precision plan (round 4: fp32 in both networks + the "
+                         "split-3 rim: StreamingWrapper.forward within north_star's 1e-3 of the reference on every frame); 16 = the 16-bit stream of rounds 2 / 3 "
+                         "(~7 %% faster, 1.02e-3 mean / 1.20e-3 max)")
+    ap.add_argument("--no-exact-rim", action="store_true", help="with --residual-stream 16: also run the condition embedding / stems / head / embedding MLPs "
+                                                                "with plain 16-bit operands (the round-3 arithmetic: 1.15e-3 / 1.38e-3)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the per-step network evaluation from a hipGraph captured at the second Euler step of every chunk (sampling.EulerEDMSampler(use_graph=True))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -643,8 +708,11 @@ def main():
     from streamingt2v_amd.streaming_svd import StreamingSVD
     parallel.init_from_env(backend="gloo" if share else "nccl", device=device)
     ops.set_element_dtype(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
-    if args.residual_stream is not None:
-        ops.set_stream_f32(args.residual_stream == "fp32")
+    if args.residual_stream == "fp32":
+        ops.set_stream_f32(True)
+    elif args.residual_stream == "16":
+        ops.set_stream_f32(False)
+        ops.set_precision_plan(exact_rim=not args.no_exact_rim, cn_stream_f32=not args.no_exact_rim, stream_f32_min_ch=0)
     if args.workload == "stage1":
         return run_stage1(args, rank, world, device)
     if args.workload == "full":

@@ -243,8 +243,9 @@ int svd_permute_rows(const void* X, void* Y, int32_t n0, int32_t n1, int32_t n2,
                      int32_t p3, int64_t row_bytes, svd_stream_t stream);
 /* fp32 -> 16-bit cast, optionally through SiLU (emb_layers' leading SiLU, openaimodel.py:284-290) */
 int svd_cast_f32(const float* X, svd_bf16* Y, int64_t n, int32_t apply_silu, int32_t dtype, svd_stream_t stream);
-/* sinusoidal embedding [cos | sin], freqs = exp(-ln(max_period) * i / half)  (util.py:207-231) -> bf16 [n][dim] */
-int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, svd_bf16* Y,
+/* sinusoidal embedding [cos | sin], freqs = exp(-ln(max_period) * i / half)  (util.py:207-231) -> 16-bit [n][dim], or fp32 with
+ * dtype = SVD_DTYPE_F32 (ABI v7: the precision plan's embedding MLPs take it in fp32) */
+int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, void* Y,
                            int32_t dtype, svd_stream_t stream);
 
 /* ---- sampler glue (Denoiser + LinearPredictionGuider + Euler step) ------------------------------------------

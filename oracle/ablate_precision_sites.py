@@ -141,9 +141,19 @@ def main():
         z = zone_now(w)
         return r(ln(x, shape, w, b, eps), "norm_out", z)
 
+    round_p = [False]
+
     def f_sdpa(q, k, v, *aa, **kw):
         z = zone_now()
-        return r(sdpa(r(q, "attn_in", z), r(k, "attn_in", z), r(v, "attn_in", z), *aa, **kw), "attn_out", z)
+        q, k, v = r(q, "attn_in", z), r(k, "attn_in", z), r(v, "attn_in", z)
+        if round_p[0]:
+            # what the MFMA attention kernels do on top: the probabilities are a 16-bit MFMA operand of P V (un-normalised: exp(s - max) in (0, 1],
+            # the row sum divides the fp32 accumulator afterwards)
+            sc = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+            pmat = torch.exp(sc - sc.amax(-1, keepdim=True))
+            o = (r(pmat, "attn_p", z) @ v) / pmat.sum(-1, keepdim=True)
+            return r(o, "attn_out", z)
+        return r(sdpa(q, k, v, *aa, **kw), "attn_out", z)
 
     F.linear, F.conv2d, F.conv3d, F.group_norm, F.layer_norm, F.scaled_dot_product_attention = f_lin, f_c2, f_c3, f_gn, f_ln, f_sdpa
 
@@ -171,6 +181,21 @@ def main():
             exact_kinds.clear(); exact_kinds.update(ks)
             m, x = err()
             print(f"  exact {name:36s}: mean {m:.3e} max {x:.3e}   share of mean^2 {1 - (m / base[0]) ** 2:6.1%}", flush=True)
+    elif a.mode == "attnp":
+        round_p[0] = True
+        m, x = err()
+        print(f"  + attention probabilities rounded to {a.dtype} before P V (the kernels' extra operand rounding): mean {m:.3e} max {x:.3e}   "
+              f"mean^2 grows by {(m / base[0]) ** 2 - 1:6.1%}", flush=True)
+        OUT = {"lin_out", "conv_out", "norm_out", "attn_out"}
+        for name, rl in {"rim (cond_embed, stems, head, emb) exact": [("controlnet.cond_embed", None), ("controlnet.stem", None), ("controlnet.emb", None), ("head", None), ("stem", None), ("emb", None)],
+                         "rim exact + ControlNet outputs exact": [("controlnet.cond_embed", None), ("controlnet.stem", None), ("controlnet.emb", None), ("head", None), ("stem", None), ("emb", None), ("controlnet", OUT)],
+                         "rim + CN outputs + UNet outputs at >= 640 channels exact": [("controlnet.cond_embed", None), ("controlnet.stem", None), ("controlnet.emb", None), ("head", None), ("stem", None), ("emb", None), ("controlnet", OUT)]
+                         + [(z, OUT) for z in ["input_blocks.%d" % i for i in range(4, 12)] + ["middle"] + ["output_blocks.%d" % i for i in range(0, 9)]],
+                         "rim + CN outputs + UNet outputs at 1280 channels exact": [("controlnet.cond_embed", None), ("controlnet.stem", None), ("controlnet.emb", None), ("head", None), ("stem", None), ("emb", None), ("controlnet", OUT)]
+                         + [(z, OUT) for z in ["input_blocks.%d" % i for i in range(7, 12)] + ["middle"] + ["output_blocks.%d" % i for i in range(0, 6)]]}.items():
+            rules[:] = rl
+            m2, x2 = err()
+            print(f"  {name:70s}: mean {m2:.3e} max {x2:.3e}   share of mean^2 {1 - (m2 / m) ** 2:6.1%}", flush=True)
     elif a.mode == "combos":
         OUT = {"lin_out", "conv_out", "norm_out", "attn_out"}
         W = {"lin_w", "conv_w"}

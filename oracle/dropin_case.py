@@ -64,8 +64,11 @@ def _conditioner(M):
     ])
 
 
-def run(swap, monkeypatch=None):
-    """-> frames [T, 3, H, W] fp32 in [-1, 1] of one conditional chunk (STEPS Euler steps + decode + clamp)."""
+def run(swap, monkeypatch=None, record=None):
+    """-> frames [T, 3, H, W] fp32 in [-1, 1] of one conditional chunk (STEPS Euler steps + decode + clamp).
+    record: a list -> every call the reference's code makes on `inference_model` (Denoiser: network(input * c_in, c_noise, cond, **kw)) and on
+    `first_stage_model.decoder` (AutoencodingEngine.decode: decoder(z, timesteps=n)) is appended as (kind, args, kwargs, output) -- the fixture
+    tests/test_gpu_dropin.py replays through the HIP mirrors on the GPU box, where /root/reference does not exist."""
     from oracle import ar_bootstrap
     from oracle.cases import TINY_UNET, tiny_unet_kwargs
     c = CASE
@@ -125,6 +128,14 @@ def run(swap, monkeypatch=None):
     for name in ("get_batch_sgm", "get_unique_embedder_keys_from_conditioner", "decode_first_stage"):
         object.__setattr__(model, name, types.MethodType(getattr(Ref, name), model))
 
+    if record is not None:
+        cl = lambda v: (v.detach().clone() if torch.is_tensor(v) else ({k: cl(x) for k, x in v.items()} if isinstance(v, dict) else v))
+        model.inference_model.register_forward_hook(
+            lambda m, args, kwargs, out: record.append(("network", [cl(x) for x in args], {k: cl(x) for k, x in kwargs.items()}, cl(out))), with_kwargs=True)
+        dec.register_forward_hook(
+            lambda m, args, kwargs, out: record.append(("decoder", [cl(x) for x in args], {k: cl(x) for k, x in kwargs.items()}, cl(out))), with_kwargs=True)
+        record.append(("sigmas", [sampler.discretization(STEPS, device="cpu").double().clone()], {}, None))
+        record.append(("guider_scale", [sampler.guider.scale.clone()], {}, None))
     undo = None
     if swap:
         # ------------------------------------------------------------------ INTEGRATION.md section 1, verbatim in substance --------------

@@ -45,11 +45,11 @@ def load_by_name(module, seed):
     return module
 
 
-def case_inputs():
-    """identical to the fixture of tests/test_gpu_ar_parity.py"""
+def case_inputs(seed=2718):
+    """identical to the fixture of tests/test_gpu_ar_parity.py (seed 2718: the original case; --seeds: more noise / image / vector draws)"""
     tu = cases.TINY_UNET
     T = tu["T"]
-    g = torch.Generator(); g.manual_seed(2718)
+    g = torch.Generator(); g.manual_seed(seed)
     noises = [torch.randn(T, 4, tu["h"], tu["w"], generator=g) for _ in range(3)]
     image = torch.rand(3, 8 * tu["h"], 8 * tu["w"], generator=g) * 2 - 1
     vector = (torch.randn(1, 768, generator=g) * 0.5).repeat(T, 1)
@@ -66,6 +66,9 @@ def conditioner(frame, vector, T):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, nargs="+", default=[2, 30])
+    ap.add_argument("--seeds", type=int, nargs="+", default=None,
+                    help="extra input seeds -> tests/golden/ar_autocast_envelope_seeds.pt ({seed: {steps: ...}}); default: the original case (seed 2718) "
+                         "-> ar_autocast_envelope.pt")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
     from models.control.controlnet import ControlNet
@@ -86,8 +89,8 @@ def main():
                                     video_kernel_size=[3, 1, 1]).eval(), 3)
     wrap = StreamingWrapper(diffusion_model=unet, controlnet=cn, num_frame_conditioning=Tc)
     den = Denoiser({"target": "models.svd.sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
-    noises, image, vector = case_inputs()
     zeros_ioi = torch.zeros(2, T)
+    inputs = {}
 
     def sampler(steps, disc, min_scale):
         return EulerEDMSampler(s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, num_steps=steps, verbose=False, device="cpu",
@@ -101,6 +104,7 @@ def main():
 
     def run(steps, autocast):
         import contextlib
+        noises, image, vector = inputs["case"]
         ac = (lambda: torch.autocast("cpu", dtype=torch.float16)) if autocast else contextlib.nullcontext
 
         def net_noctrl(x, t, c, **kw):                           # chunk 0: the same VideoUNet without ControlNet / CAM (video_model.py:582,603)
@@ -128,24 +132,32 @@ def main():
         return torch.cat(chunks, 0)
 
     from oracle.range_oracle import frames_to_uint8
-    out = {"case": dict(T=T, Tc=Tc, tv=TV, seed=2718), "steps": {}}
     bounds = [0, T, T + (T - Tc), T + 2 * (T - Tc)]
-    for steps in a.steps:
-        t0 = time.time()
-        ref = run(steps, False)[:, :, ::2, ::2].contiguous()      # every second pixel in both directions: a 4x smaller fixture; all statistics
-        t1 = time.time()                                          # (here and in the GPU test) are taken on this subset
-        amp = run(steps, True)[:, :, ::2, ::2].contiguous()
-        e = (amp - ref).flatten(1).pow(2).mean(1).sqrt()
-        lvl = (frames_to_uint8(amp).int() - frames_to_uint8(ref).int()).abs()
-        env = dict(l2_max=[e[bounds[i]:bounds[i + 1]].max().item() for i in range(3)], l2_mean=[e[bounds[i]:bounds[i + 1]].mean().item() for i in range(3)],
-                   u8_frac_gt1=(lvl > 1).float().mean().item(), u8_frac_gt0=(lvl > 0).float().mean().item(), u8_max=int(lvl.max()))
-        print(f"[reference fp16 autocast vs its own fp32, {steps} steps, chunk 0 + 2 AR chunks] per-frame L2 max per chunk "
-              f"{env['l2_max'][0]:.3e} {env['l2_max'][1]:.3e} {env['l2_max'][2]:.3e} | mean {env['l2_mean'][0]:.3e} {env['l2_mean'][1]:.3e} {env['l2_mean'][2]:.3e} | "
-              f"uint8: {100 * env['u8_frac_gt1']:.3f} % of bytes differ by > 1 level ({100 * env['u8_frac_gt0']:.2f} % by >= 1), max {env['u8_max']} "
-              f"({t1 - t0:.0f} s fp32 + {time.time() - t1:.0f} s autocast)", flush=True)
-        out["steps"][steps] = dict(video_sub=ref.clone(), envelope=env)
-    path = os.path.join(ROOT, "tests", "golden", "ar_autocast_envelope.pt")
-    torch.save(out, path)
+    allout = {}
+    for seed in (a.seeds or [2718]):
+      inputs["case"] = case_inputs(seed)
+      out = {"case": dict(T=T, Tc=Tc, tv=TV, seed=seed), "steps": {}}
+      allout[seed] = out
+      for steps in a.steps:
+          t0 = time.time()
+          ref = run(steps, False)[:, :, ::2, ::2].contiguous()      # every second pixel in both directions: a 4x smaller fixture; all statistics
+          t1 = time.time()                                          # (here and in the GPU test) are taken on this subset
+          amp = run(steps, True)[:, :, ::2, ::2].contiguous()
+          e = (amp - ref).flatten(1).pow(2).mean(1).sqrt()
+          lvl = (frames_to_uint8(amp).int() - frames_to_uint8(ref).int()).abs()
+          env = dict(l2_max=[e[bounds[i]:bounds[i + 1]].max().item() for i in range(3)], l2_mean=[e[bounds[i]:bounds[i + 1]].mean().item() for i in range(3)],
+                     u8_frac_gt1=(lvl > 1).float().mean().item(), u8_frac_gt0=(lvl > 0).float().mean().item(), u8_max=int(lvl.max()))
+          print(f"[reference fp16 autocast vs its own fp32, seed {seed}, {steps} steps, chunk 0 + 2 AR chunks] per-frame L2 max per chunk "
+                f"{env['l2_max'][0]:.3e} {env['l2_max'][1]:.3e} {env['l2_max'][2]:.3e} | mean {env['l2_mean'][0]:.3e} {env['l2_mean'][1]:.3e} {env['l2_mean'][2]:.3e} | "
+                f"uint8: {100 * env['u8_frac_gt1']:.3f} % of bytes differ by > 1 level ({100 * env['u8_frac_gt0']:.2f} % by >= 1), max {env['u8_max']} "
+                f"({t1 - t0:.0f} s fp32 + {time.time() - t1:.0f} s autocast)", flush=True)
+          out["steps"][steps] = dict(video_sub=ref.clone(), envelope=env)
+    if a.seeds:
+        path = os.path.join(ROOT, "tests", "golden", "ar_autocast_envelope_seeds.pt")
+        torch.save(allout, path)
+    else:
+        path = os.path.join(ROOT, "tests", "golden", "ar_autocast_envelope.pt")
+        torch.save(out, path)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 

@@ -16,7 +16,8 @@ from oracle import dropin_case  # noqa: E402
 
 
 def main():
-    ref = dropin_case.run(swap=False)
+    calls = []
+    ref = dropin_case.run(swap=False, record=calls)
     got = dropin_case.run(swap=True)
     e = (got - ref).flatten(1).pow(2).mean(1).sqrt()
     print(f"[executed drop-in] reference code around OUR StreamingWrapper / VideoDecoder vs around its own: per-frame L2 max {e.max():.3e} "
@@ -25,6 +26,14 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "dropin_tiny.pt")
     torch.save(dict(frames=ref.clone(), steps=dropin_case.STEPS, case=dropin_case.CASE), path)
     print("wrote", path, os.path.getsize(path), "bytes")
+    # the calls the reference's own sampler / denoiser / decode_first_stage made on the two hot-path objects, for the HIP-side replay
+    kinds = [c[0] for c in calls]
+    assert kinds.count("network") == dropin_case.STEPS and kinds.count("decoder") >= 1, kinds
+    pack = lambda v: v                                                  # fp32 as recorded (the whole fixture is ~1.5 MB)
+    path = os.path.join(ROOT, "tests", "golden", "dropin_calls_tiny.pt")
+    torch.save(dict(calls=[(k, [pack(a) for a in args], {n: pack(x) for n, x in kw.items()}, pack(out)) for k, args, kw, out in calls],
+                    steps=dropin_case.STEPS, case=dropin_case.CASE), path)
+    print("wrote", path, os.path.getsize(path), "bytes;", kinds)
 
 
 if __name__ == "__main__":

@@ -79,3 +79,41 @@ def blend_step_sharded(latents, denoise_chunk, chunk_size, overlap_size, n_chunk
     parallel.all_gather(recv, send, group=group)
     outs = [recv[idx % world][idx // world] for idx in range(n_chunks)]
     return _apply(torch.empty_like(latents), outs, starts, offsets, chunk_size)
+
+
+def blend_step_units_sharded(latents, predict_half, combine, chunk_size, overlap_size, n_chunks, rng, group=None):
+    """The step with (window, CFG half) UNITS sharded over the ranks (round 4): the shipped 100-frame job has only 3 blending windows, so window
+    sharding (blend_step_sharded) leaves 5 of 8 GPUs idle; the two CFG halves of a window's UNet evaluation never interact (per-sample norms and
+    attention, pipeline_i2vgen_xl.py:851-874: one batched call on cat([latents] * 2)), which makes 2 * n_chunks independent units per DDIM step.
+
+    predict_half(idx, half, window) -> raw UNet prediction of CFG half `half` (0 = unconditional, 1 = text) for window idx, any shape;
+    combine(idx, window, pred_uncond, pred_text) -> the window after guidance + scheduler step.
+    Unit u = 2 * idx + half goes to rank u % world; ONE all-gather of the predictions per step (8.75 MB per unit at the shipped sizes), then
+    every rank applies guidance + DDIM (a 9-MB element-wise kernel per window) and the overwrites in window order: all ranks end with the
+    full latents, bit-identical to the single-process loop whenever a half evaluated alone equals its half of the batched evaluation."""
+    import torch.distributed as dist
+    from . import parallel
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    starts = chunk_starts(latents.shape[2], chunk_size, overlap_size, n_chunks)
+    offsets = draw_offsets(n_chunks, overlap_size, rng)          # identical on all ranks (same generator state)
+    n_units = 2 * n_chunks
+    per_rank = (n_units + world - 1) // world
+    windows = [latents[:, :, s:s + chunk_size] for s in starts]
+    mine, proto = [], None
+    for slot in range(per_rank):
+        u = slot * world + rank
+        if u < n_units:
+            p = predict_half(u // 2, u % 2, windows[u // 2]).contiguous()
+            proto = p
+            mine.append(p)
+        else:
+            mine.append(None)
+    if proto is None:                                             # a rank without any unit (world > 2 * n_chunks) still joins the collective
+        w0 = windows[0]                                           # prediction of a window [B, C, chunk, H, W]: frames-major [chunk, C, H, W]
+        proto = torch.zeros((w0.shape[2], w0.shape[1]) + tuple(w0.shape[3:]), dtype=latents.dtype, device=latents.device)
+    send = torch.stack([m if m is not None else torch.zeros_like(proto) for m in mine], 0)      # [per_rank, ...]
+    recv = [torch.empty_like(send) for _ in range(world)]
+    parallel.all_gather(recv, send, group=group)
+    pred = lambda u: recv[u % world][u // world]
+    outs = [combine(idx, windows[idx], pred(2 * idx), pred(2 * idx + 1)) for idx in range(n_chunks)]
+    return _apply(torch.empty_like(latents), outs, starts, offsets, chunk_size)

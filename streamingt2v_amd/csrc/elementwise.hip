@@ -134,18 +134,26 @@ __global__ void cast_f32_kernel(const float* __restrict__ X, svd_bf16* __restric
     }
 }
 
-template <class E>
+template <class E, bool F32OUT>
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, int dim, float log_max_period,
-                                          svd_bf16* __restrict__ Y) {
+                                          void* __restrict__ Yv) {
     const int half = dim >> 1;
     const int64_t total = (int64_t)n * half;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / half), k = (int)(i - (int64_t)r * half);
         const float freq = expf(-log_max_period * (float)k / (float)half);
         const float a = t[r] * freq;
-        Y[(int64_t)r * dim + k] = E::from_f32(cosf(a));
-        Y[(int64_t)r * dim + half + k] = E::from_f32(sinf(a));
-        if ((dim & 1) && k == 0) Y[(int64_t)r * dim + dim - 1] = 0;
+        if constexpr (F32OUT) {          // the precision plan's embedding MLPs take the embedding in fp32 (split-3 operands, csrc/precision.hip)
+            float* Y = (float*)Yv;
+            Y[(int64_t)r * dim + k] = cosf(a);
+            Y[(int64_t)r * dim + half + k] = sinf(a);
+            if ((dim & 1) && k == 0) Y[(int64_t)r * dim + dim - 1] = 0.f;
+        } else {
+            svd_bf16* Y = (svd_bf16*)Yv;
+            Y[(int64_t)r * dim + k] = E::from_f32(cosf(a));
+            Y[(int64_t)r * dim + half + k] = E::from_f32(sinf(a));
+            if ((dim & 1) && k == 0) Y[(int64_t)r * dim + dim - 1] = 0;
+        }
     }
 }
 
@@ -336,10 +344,14 @@ extern "C" int svd_cast_f32(const float* X, svd_bf16* Y, int64_t n, int32_t appl
     return SVD_OK;
 }
 
-extern "C" int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, svd_bf16* Y, int32_t dtype,
+extern "C" int svd_timestep_embedding(const float* t, int32_t n, int32_t dim, float max_period, void* Y, int32_t dtype,
                                       svd_stream_t stream) {
     if (!t || !Y || n <= 0 || dim < 2) return SVD_EINVAL;
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(timestep_embedding_kernel<E>, dim3(grid_for((int64_t)n * (dim / 2))), dim3(256), 0,
+    if (dtype == SVD_DTYPE_F32) {
+        hipLaunchKernelGGL((timestep_embedding_kernel<ElemF16, true>), dim3(grid_for((int64_t)n * (dim / 2))), dim3(256), 0, (hipStream_t)stream, t, n, dim,
+                           logf(max_period), Y);
+    } else
+    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((timestep_embedding_kernel<E, false>), dim3(grid_for((int64_t)n * (dim / 2))), dim3(256), 0,
                                                  (hipStream_t)stream, t, n, dim, logf(max_period), Y));
     SVD_CHECK_LAUNCH("timestep_embedding");
     return SVD_OK;

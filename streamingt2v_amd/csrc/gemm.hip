@@ -95,7 +95,8 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
         if (a.R || a.S || a.rowvec || a.epi_flags) return SVD_EINVAL;
     }
     if (a.epi_flags & SVD_EPI_GEGLU) {
-        if (a.N % 64 != 0 || a.out_mode != SVD_OUT_BF16) return SVD_EINVAL;
+        // GEGLU projections write 16 bit and take no fp32 residual: the fp32-stream kernel has no GEGLU pass (it would store N/2-wide rows as N columns)
+        if (a.N % 64 != 0 || a.out_mode != SVD_OUT_BF16 || a.res_f32) return SVD_EINVAL;
     }
     int cfg = a.tile_cfg > 0 ? a.tile_cfg : pick_cfg(a);
     if (a.tile_cfg > 0 && ((a.a_mode == SVD_A_CONV3X3 && a.ups) || a.res_f32 || a.out_mode == SVD_OUT_F32) && svd_gemm_config_valid(args, cfg) != 1)

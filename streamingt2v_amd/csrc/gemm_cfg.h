@@ -15,7 +15,7 @@ namespace svd_gemm_detail {
 #ifndef SVD_GEMM_FRAG_SETS_MAX
 #define SVD_GEMM_FRAG_SETS_MAX 2      /* 1: A/B switch, single fragment set, scheduler's own order */
 #endif
-template <int BM_, int BN_, int WM_, int WN_, int BK_, bool GLDS_, bool TRANS_, int NS_ = 2, bool DELAY_ = false, bool PP_ = false, bool LEAN_AUX_ = false>
+template <int BM_, int BN_, int WM_, int WN_, int BK_, bool GLDS_, bool TRANS_, int NS_ = 2, bool DELAY_ = false, bool PP_ = false>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
     static constexpr bool GLDS = GLDS_, TRANS = TRANS_;
@@ -24,7 +24,7 @@ struct GemmCfg {
     static constexpr int GROUPS = PINGPONG ? 2 : 1;  // ping-pong: two independent wave groups per workgroup, half an iteration apart
     static constexpr int THREADS = NT * GROUPS;
     // register budget: 4-wave workgroups with <= 64 accumulator registers per lane must fit twice per SIMD (2 WG / CU)
-    static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && !LEAN_AUX_ && WM * WN == 4 && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64 || BK_ == 32)) ? ((BK_ == 32 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? SVD_GEMM_BK32_WAVES : 2) : 1;   // BK 32 + 128 accumulators: 2 x 58 KB LDS, 256 registers
+    static constexpr int MIN_WAVES_PER_SIMD = (!PP_ && WM * WN == 4 && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64 || BK_ == 32)) ? ((BK_ == 32 && (BM / WM / 32) * (BN / WN / 32) * 16 <= 64) ? SVD_GEMM_BK32_WAVES : 2) : 1;   // BK 32 + 128 accumulators: 2 x 58 KB LDS, 256 registers
     static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     // tiles that also carry the folded-upsample convolution kernel (the Upsample layers of the UNet and of the VAE decoder): the heuristic's
     // picks and the shapes the tuner has chosen for those layers -- not all 22, to bound build time
@@ -56,13 +56,11 @@ struct GemmCfg {
     static constexpr bool DELAYED_EPI = DELAY_ && !TRANS_ && ((BM / WM / 32) * (BN / WN / 32) * 16 <= 64);
     static constexpr bool EPI_DEDICATED = DELAYED_EPI || (WM * WN * EPI_WAVE_BYTES > STAGE_BYTES);   // else: reuse the consumed stage buffer
     // aux slots: bias slice + per-frame vectors of up to AUX_NRV frames, DMA'd at tile setup (2 slots: current / prefetched tile)
-    // LEAN_AUX (round 4, the deep BK 32 rings that fill the LDS): 2 per-frame vector rows and 2 aux slots.  Two slots suffice for ANY ring depth: a
-    // prologue requests K tiles of ONE output tile, the prologue of tile i+1 runs before the epilogue of tile i and the one of tile i+2 after it.
-    static constexpr int AUX_NRV = (2 * (BM_ + BN_) * BK_ * 2 >= 144 * 1024 || LEAN_AUX_) ? 2 : 4;   // fewer per-frame vector rows when the stage ring leaves < 16 KB
+    static constexpr int AUX_NRV = (2 * (BM_ + BN_) * BK_ * 2 >= 144 * 1024) ? 2 : 4;   // fewer per-frame vector rows when the stage ring leaves < 16 KB
     static constexpr int AUX_INSTR = (BN + 255) / 256;
     static constexpr int AUX_SLOT_BYTES = (1 + AUX_NRV) * AUX_INSTR * 1024;
     static constexpr int AUX_OFF = LDS_BYTES + (EPI_DEDICATED ? WM * WN * EPI_WAVE_BYTES : 0);
-    static constexpr int AUX_SLOTS = (LEAN_AUX_ ? 2 : NSTAGE) + (DELAYED_EPI ? 1 : 0);   // one per tile the load stream can be ahead (+1: the delayed tile); see LEAN_AUX
+    static constexpr int AUX_SLOTS = NSTAGE + (DELAYED_EPI ? 1 : 0);   // one per tile the load stream can be ahead (+1: the delayed tile)
     static constexpr int LAUNCH_LDS = AUX_OFF + (TRANS_ ? 0 : AUX_SLOTS * AUX_SLOT_BYTES);
     static constexpr int TOTAL_LDS = GROUPS * LAUNCH_LDS;            // LAUNCH_LDS: bytes of ONE group
     static_assert(TOTAL_LDS <= 160 * 1024, "tile configuration exceeds the 160 KiB LDS of a CU");
@@ -88,8 +86,7 @@ struct GemmCfg {
     X(10, 256, 128, 2, 2, 64, true, false, 2)      /* 4 waves, 128x64 per wave                             */ \
     X(14, 256, 160, 4, 1, 64, true, false, 2)      /* N = 320 as 2 tiles, 64x160 per wave                  */ \
     X(18, 256, 128, 4, 2, 64, true, false, 3)      /* 3-stage ring (144 KB)                                        */ \
-    X(22, 128, 320, 4, 2, 64, true, false, 2)      /* same, 32x160 per wave                                                                 */ \
-    X(24, 128, 320, 2, 2, 32, true, false, 104)    /* round 4: 4 with BK 32 and a ring of FOUR half-K-tiles (124 KB, lean aux): three K tiles in flight for the HBM-side N = 320 GEMMs (8 waves x BK 32 cannot stage 320 rows: 128 rows per pass) */
+    X(22, 128, 320, 4, 2, 64, true, false, 2)      /* same, 32x160 per wave                                                                 */
 #define SVD_GEMM_CONFIGS_P2(X)                                                            \
     X(3, 128, 64, 2, 2, 64, true, false, 2)        /* narrow N                                             */ \
     X(7, 128, 128, 2, 2, 64, true, true, 2)        /* transposed output (V^T for attention)                */ \
@@ -102,8 +99,7 @@ struct GemmCfg {
     X(8, 256, 256, 4, 2, 64, true, false, 2)       /* 8 waves, 64x128 per wave                             */ \
     X(12, 64, 128, 2, 2, 64, true, false, 2)       /* small M                                              */ \
     X(16, 128, 192, 2, 2, 64, true, false, 2)      /* N = 960 / 1920 / 3840 exactly, 64x96 per wave        */ \
-    X(20, 256, 256, 2, 4, 64, true, false, 2)      /* 8 with 128x64 wave tiles                                                              */ \
-    X(26, 256, 256, 2, 4, 32, true, false, 103)    /* round 4: 20 with a ring of three half-K-tiles (loads two K tiles ahead; 108 KB)        */
+    X(20, 256, 256, 2, 4, 64, true, false, 2)      /* 8 with 128x64 wave tiles                                                              */
 #define SVD_GEMM_CONFIGS(X) SVD_GEMM_CONFIGS_P0(X) SVD_GEMM_CONFIGS_P1(X) SVD_GEMM_CONFIGS_P2(X) SVD_GEMM_CONFIGS_P3(X)
 #else
 #define SVD_GEMM_CONFIGS_P0(X) SVD_GEMM_CONFIGS(X)
@@ -111,9 +107,9 @@ struct GemmCfg {
 #define SVD_GEMM_CONFIGS_P2(X)
 #define SVD_GEMM_CONFIGS_P3(X)
 #endif
-constexpr int kNumCfg = 26;   /* ids 1..26, 25 unused */
+constexpr int kNumCfg = 23;
 
-#define X(id, bm, bn, wm, wn, bk, glds, tr, ns) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr, (ns) % 10, ((((ns) / 10) % 10) & 1) != 0, ((((ns) / 10) % 10) & 2) != 0, ((ns) / 100) != 0>;   /* tens digit: 1 = delayed epilogue, 2 = ping-pong; hundreds digit: lean aux */
+#define X(id, bm, bn, wm, wn, bk, glds, tr, ns) using Cfg##id = GemmCfg<bm, bn, wm, wn, bk, glds, tr, (ns) % 10, (((ns) / 10) & 1) != 0, (((ns) / 10) & 2) != 0>;   /* tens digit: 1 = delayed epilogue, 2 = ping-pong */
 SVD_GEMM_CONFIGS(X)
 #undef X
 

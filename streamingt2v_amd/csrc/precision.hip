@@ -77,6 +77,29 @@ __global__ __launch_bounds__(256) void rows_split3_kernel(const float* __restric
         gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
         bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
     }
+    if (octets > LPR) {
+        // wide rows without LayerNorm (the embedding MLPs' 768 / 1280-wide activations): no row statistics, so every octet is independent
+        for (int64_t row0 = wave_id * RW; row0 < rows; row0 += nwaves * RW) {
+            const int64_t row = row0 + rsel;
+            if (row >= rows) continue;
+            for (int o = sub; o < octets; o += LPR) {
+                const float* xp = X + row * ldx + o * 8;
+                const float4 a = *(const float4*)xp, b = *(const float4*)(xp + 4);
+                float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                if (do_silu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
+                }
+                uint4 hi, lo;
+                split_hi_lo<E>(v, hi, lo);
+                svd_bf16* y = Y + row * ldy + o * 8;
+                *(uint4*)y = hi;
+                *(uint4*)(y + channels) = lo;
+                *(uint4*)(y + 2 * channels) = hi;
+            }
+        }
+        return;
+    }
     for (int64_t row0 = wave_id * RW; row0 < rows; row0 += nwaves * RW) {
         const bool live = row0 + rsel < rows;
         const int64_t row = live ? row0 + rsel : rows - 1;
@@ -260,8 +283,8 @@ extern "C" int svd_nchw_to_tokens_x3(const float* X0, int32_t c0, const float* X
 
 extern "C" int svd_rows_split3(const float* X, int64_t ldx, svd_bf16* Y, int64_t ldy, int64_t rows, int32_t channels, const float* gamma,
                                const float* beta, float eps, int32_t flags, int32_t dtype, svd_stream_t stream) {
-    if (!X || !Y || rows <= 0 || channels <= 0 || channels % 8 || channels > 512 || ldx % 4 || ldy % 8 || ldy < 3 * channels) return SVD_EINVAL;
-    if ((flags & SVD_SPLIT3_LAYERNORM) && (!gamma || !beta)) return SVD_EINVAL;
+    if (!X || !Y || rows <= 0 || channels <= 0 || channels % 8 || channels > 4096 || ldx % 4 || ldy % 8 || ldy < 3 * channels) return SVD_EINVAL;
+    if ((flags & SVD_SPLIT3_LAYERNORM) && (!gamma || !beta || channels > 512)) return SVD_EINVAL;      // row statistics: one octet per lane
     if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return SVD_EINVAL;
     const int octets = channels / 8;
     const int lpr = octets <= 4 ? 4 : octets <= 8 ? 8 : octets <= 16 ? 16 : octets <= 32 ? 32 : 64;

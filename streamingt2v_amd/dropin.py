@@ -41,10 +41,16 @@ class VideoDecoderModule(HipModule):
     whether to pass `timesteps=`: `install` rebinds the module-level name `VideoDecoder` of the reference's streaming_svd.py to this class."""
 
 
-def install(model, device="cuda", unet_cfg=None, vae_cfg=None, state_dict=None):
+def install(model, device="cuda", unet_cfg=None, vae_cfg=None, state_dict=None, offload_reference=False):
     """model: the reference's StreamingSVD module AFTER its strict checkpoint load.  Builds the MI355X mirrors from the same weights
     (`model.diffusion_model.*`, `controlnet.*`, `first_stage_model.decoder.*`; strict) and swaps the two hot-path objects in place.
-    Returns (wrapper, decoder): the wrapped streamingt2v_amd objects."""
+    Returns (wrapper, decoder): the wrapped streamingt2v_amd objects.
+
+    The reference's own `model.model` (the UNet wrapper) and `model.controlnet` stay REGISTERED children of `model` after the swap: their
+    weights are not used by the hot path any more but stay wherever they were -- on a GPU that is ~9 GB fp32 next to the packed 16-bit copies,
+    and `model.state_dict()` / `.to()` / `.half()` keep operating on them (the mirrors do not follow such calls: re-run install() after changing
+    weights).  offload_reference=True moves those two modules (and nothing else) to the CPU and empties the allocator cache; the state dict
+    stays complete."""
     from .temporal_ae import VaeConfig, VideoDecoder
     from .video_model import ControlNet, UNetConfig, VideoUNet
     from .wrappers import StreamingWrapper
@@ -58,4 +64,12 @@ def install(model, device="cuda", unet_cfg=None, vae_cfg=None, state_dict=None):
     ref_module = sys.modules.get(type(model).__module__)
     if ref_module is not None and hasattr(ref_module, "VideoDecoder"):
         ref_module.VideoDecoder = VideoDecoderModule                 # the isinstance at streaming_svd.py:138
+    if offload_reference:
+        import torch
+        for name in ("model", "controlnet"):
+            m = getattr(model, name, None)
+            if isinstance(m, nn.Module):
+                m.to("cpu")
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
     return wrapper, dec

@@ -113,8 +113,31 @@ class I2VEnhancer:
         out = ops.ddim_cfg_step(fr, pred[:Fr].contiguous(), pred[Fr:].contiguous(), self.g, a_t, a_prev, self.sched.v_prediction)
         return out.permute(1, 0, 2, 3)[None]
 
-    def denoise(self, video_latents, noise, conds, chunk_size, overlap_size, rng=random, group=None):
-        """video_latents / noise fp32 [1, 4, F, h, w]; conds: one dict per window.  Returns the enhanced latents."""
+    # ---- (window, CFG half) units: what a rank evaluates when the step is sharded over a process group (blending.blend_step_units_sharded) ----
+    def _predict_half(self, window, t, cond, half):
+        """Raw UNet prediction [chunk, 4, h, w] of ONE CFG half (0 = unconditional, 1 = text) of a window: the batch-1 evaluation with that
+        half's conditioning.  Equal to its half of the batched evaluation of _denoise_window (per-sample norms and attention)."""
+        key = (id(cond), half)
+        const = self._consts.get(key)
+        if const is None:
+            sl = slice(half, half + 1)
+            const = self._consts[key] = self.unet.set_conditioning(cond["fps"][sl], cond["image_latents"][sl], cond["image_embeddings"][sl],
+                                                                 cond["text"][sl])
+        self.unet.use_conditioning(const)
+        fr = window[0].permute(1, 0, 2, 3).contiguous()
+        return self.unet.forward_frames(fr, t)
+
+    def _combine_halves(self, window, t, pred_uncond, pred_text):
+        """guidance (pipeline_i2vgen_xl.py:870-874) + DDIMScheduler.step (:884-885) on a window, from the two halves' predictions."""
+        fr = window[0].permute(1, 0, 2, 3).contiguous()
+        a_t, a_prev = self.sched.alphas(t)
+        out = ops.ddim_cfg_step(fr, pred_uncond.contiguous(), pred_text.contiguous(), self.g, a_t, a_prev, self.sched.v_prediction)
+        return out.permute(1, 0, 2, 3)[None]
+
+    def denoise(self, video_latents, noise, conds, chunk_size, overlap_size, rng=random, group=None, shard="units"):
+        """video_latents / noise fp32 [1, 4, F, h, w]; conds: one dict per window.  Returns the enhanced latents.
+        group: a process group -> every DDIM step is sharded over its ranks; shard = "units" (default): the 2 x n_windows (window, CFG half)
+        units round-robin (3 windows keep 6 of 8 GPUs busy), "windows": whole windows (the round-1 form: 3 of 8)."""
         ts = self.sched.get_timesteps(self.steps, self.strength)
         self._consts = {}
         latents = self.sched.add_noise(video_latents, noise, ts[0])
@@ -123,6 +146,10 @@ class I2VEnhancer:
             fn = lambda idx, w, t=t: self._denoise_window(w, t, conds[idx])
             if group is None:
                 latents = blending.blend_step(latents, fn, chunk_size, overlap_size, n_chunks, rng)
-            else:
+            elif shard == "windows":
                 latents = blending.blend_step_sharded(latents, fn, chunk_size, overlap_size, n_chunks, rng, group)
+            else:
+                ph = lambda idx, half, w, t=t: self._predict_half(w, t, conds[idx], half)
+                cb = lambda idx, w, pu, pc, t=t: self._combine_halves(w, t, pu, pc)
+                latents = blending.blend_step_units_sharded(latents, ph, cb, chunk_size, overlap_size, n_chunks, rng, group)
         return latents

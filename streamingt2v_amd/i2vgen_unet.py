@@ -32,9 +32,13 @@ class I2VConfig:
     a CrossAttnDownBlock3D (and up block n-1-i a CrossAttnUpBlock3D)."""
 
     def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
-                 norm_num_groups=32, cross_attention_dim=1024, attention_head_dim=64, attn_levels=(True, True, True, False)):
+                 norm_num_groups=32, cross_attention_dim=1024, attention_head_dim=64, attn_levels=(True, True, True, False), sample_size=None):
         assert norm_num_groups == 32 and attention_head_dim == 64, "kernels are built for 32 groups / head dim 64"
         self.in_channels, self.out_channels = in_channels, out_channels
+        # `unet.config.sample_size`: read by the pipeline for its DEFAULT height / width only (pipeline_i2vgen_xl.py:731-732: height or
+        # config.sample_size * vae_scale_factor); None like the shipped ali-vilab/i2vgen-xl unet/config.json ("sample_size": null is what the
+        # checkpoint carries as far as it is known offline) -- i2v_enhance_interface.py always passes height / width explicitly.
+        self.sample_size = sample_size
         self.block_out_channels = tuple(block_out_channels)
         self.layers_per_block = layers_per_block
         self.cross_attention_dim = cross_attention_dim
@@ -310,7 +314,7 @@ class I2VGenXLUNet:
     # -------------------------------------------------------------------------------------------- reference API shims
     @property
     def config(self):
-        """`unet.config.in_channels` / `.cross_attention_dim` as read by the pipeline (pipeline_i2vgen_xl.py:819)."""
+        """`unet.config.in_channels` / `.cross_attention_dim` / `.sample_size` as read by the pipeline (pipeline_i2vgen_xl.py:731-732,819)."""
         return self.cfg
 
     def enable_forward_chunking(self, chunk_size=None, dim=0):

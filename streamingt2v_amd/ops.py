@@ -49,18 +49,40 @@ def set_stream_f32(on=True):
 #               the UNet's head (7.5 %; GroupNorm + SiLU + conv to 4 channels) run with split-3 (~22-bit) MFMA operands / in fp32 (csrc/precision.hip);
 #   CN_STREAM_F32  the fp32 residual stream INSIDE THE CONTROLNET only (16 % of the squared error for ~1/8 of the stream's bytes: the ControlNet
 #               sees 14 of the 64 frames of a forward and only the encoder half).
-# Both are the package default; STREAM_F32 (the whole UNet's stream in fp32, +7 % job time) stays an option.
-EXACT_RIM = True
-CN_STREAM_F32 = True
+#   STREAM_F32_MIN_CH  the fp32 residual stream in the UNet blocks with at least this many channels (0 = none).  The stream's cost is its bytes: a
+#               level-0 tensor (320 channels @ 72x128) is 295 MB, level 1 147 MB, levels 2 / 3 (1280 channels) 74 / 18 MB -- the low-resolution
+#               half of the blocks carries the stream in fp32 for a fraction of what the whole UNet costs (+7 %).
+# All are package defaults (environment overrides for A/B runs: SVD_EXACT_RIM, SVD_CN_STREAM_F32, SVD_STREAM_F32_MIN_CH); STREAM_F32 (the
+# whole UNet's stream in fp32) stays an option.
+import os as _os
+EXACT_RIM = _os.environ.get("SVD_EXACT_RIM", "1") != "0"
+CN_STREAM_F32 = _os.environ.get("SVD_CN_STREAM_F32", "1") != "0"
+STREAM_F32_MIN_CH = int(_os.environ.get("SVD_STREAM_F32_MIN_CH", "320"))
+# per block kind (A/B sweeps only; None = STREAM_F32_MIN_CH): the ResBlocks' / the transformers' own threshold
+STREAM_F32_MIN_CH_KIND = {"res": None, "svt": None}
+for _k in ("res", "svt"):
+    if _os.environ.get("SVD_STREAM_F32_MIN_CH_" + _k.upper()):
+        STREAM_F32_MIN_CH_KIND[_k] = int(_os.environ["SVD_STREAM_F32_MIN_CH_" + _k.upper()])
 
 
-def set_precision_plan(exact_rim=None, cn_stream_f32=None):
+def set_precision_plan(exact_rim=None, cn_stream_f32=None, stream_f32_min_ch=None):
     """Select the round-4 precision plan (None = leave).  Like set_element_dtype: call BEFORE load_state_dict (the rim packs its own weights)."""
-    global EXACT_RIM, CN_STREAM_F32
+    global EXACT_RIM, CN_STREAM_F32, STREAM_F32_MIN_CH
     if exact_rim is not None:
         EXACT_RIM = bool(exact_rim)
     if cn_stream_f32 is not None:
         CN_STREAM_F32 = bool(cn_stream_f32)
+    if stream_f32_min_ch is not None:
+        STREAM_F32_MIN_CH = int(stream_f32_min_ch)
+
+
+def stream_on(channels, kind=None):
+    """Does a block of `channels` channels keep its residual stream in fp32?  (STREAM_F32: every block; else the precision plan's threshold.)"""
+    if STREAM_F32:
+        return True
+    m = STREAM_F32_MIN_CH_KIND.get(kind)
+    m = STREAM_F32_MIN_CH if m is None else m
+    return m > 0 and channels >= m
 
 
 class stream_scope:
@@ -418,7 +440,7 @@ def nchw_to_tokens_x3(x0, x1, scale, cpad):
 
 
 def rows_split3(x, ln=None, eps=1e-5, silu=False):
-    """fp32 rows [rows, C <= 512] -> split-3 16-bit rows [rows, 3 C]; ln = (gamma, beta): per-row LayerNorm first, then SiLU (both fp32)."""
+    """fp32 rows [rows, C] -> split-3 16-bit rows [rows, 3 C]; ln = (gamma, beta): per-row LayerNorm first (C <= 512), then SiLU (both fp32)."""
     rows, ld = _rows_ld(x)
     assert x.dtype == torch.float32
     Cc = x.shape[1]
@@ -534,9 +556,9 @@ def to_elem(x, silu=False):
 to_bf16 = to_elem   # historical name
 
 
-def timestep_embedding(t, dim, max_period=10000.0):
+def timestep_embedding(t, dim, max_period=10000.0, f32=False):
     assert t.dtype == torch.float32 and t.is_contiguous()
-    out = torch.empty((t.numel(), dim), dtype=ELEM, device=t.device)
+    out = torch.empty((t.numel(), dim), dtype=torch.float32 if f32 else ELEM, device=t.device)
     check(_lib.svd_timestep_embedding(_p(t), t.numel(), dim, float(max_period), _p(out), _dt(out), _stream()),
           "svd_timestep_embedding")
     return out

@@ -290,29 +290,46 @@ class JobPlan:
     def _preflight(self):
         """One tiny instance of every collective of the plan on the device the job will use.  Returns None or the failure text."""
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        err = None
-        try:
-            net = torch.full((4, 4), float(self.rank), device=dev)
-            got = self.cfg_exchange.gather(net)
-            assert got.shape == (8, 4)
-            if self.sp is not None:
-                sp, T, pix, C = self.sp, 2 * self.sp.size + 1, 2 * self.sp.size, 8
-                lo, hi = sp.frame_range(T)
-                full = torch.arange(T * pix * C, dtype=torch.float32, device=dev).reshape(T * pix, C).to(torch.float16)
-                mine = sp.take_frames(full, 1, T, pix)
-                back = sp.to_frames(sp.to_pixels(mine, 1, T, pix), 1, T, pix)
-                assert torch.equal(back, mine), "all-to-all round trip"
-                assert torch.equal(sp.gather_frames(mine, 1, T, pix), full), "padded all-gather"
-                sums = sp.allreduce_sums(torch.ones((1, 32, 2), dtype=torch.float64, device=dev))
-                assert float(sums[0, 0, 0]) == sp.size, "fp64 all-reduce"
-            t = torch.full((3, 5), float(self.rank), device=dev)
-            src = dist.get_global_rank(self.decode_group, 0)
-            broadcast(t, src=src, group=self.decode_group)
-            assert float(t[0, 0]) == float(src), "broadcast"
-            if dev.type == "cuda":
-                torch.cuda.synchronize()
-        except Exception as e:                      # noqa: BLE001 -- whatever the backend throws, the job must still produce a number
-            err = f"{type(e).__name__}: {e}"
+        # Every rank issues EVERY collective of the sequence, in the same order, whatever its local checks say: a rank that stopped at a failed
+        # check would leave the others waiting inside the next collective (a mismatched sequence hangs RCCL instead of raising).  Local
+        # failures are only RECORDED here and exchanged by the flag all-reduce below.  (A backend that hangs inside a collective cannot be
+        # caught from here at all: the launcher's timeout is the backstop.)
+        errs = []
+
+        def step(what, fn):
+            try:
+                return fn()
+            except Exception as e:                  # noqa: BLE001 -- whatever the backend throws, the job must still produce a number
+                errs.append(f"{what}: {type(e).__name__}: {e}")
+                return None
+
+        def expect(cond, what):
+            if not cond:
+                errs.append(what)
+
+        net = torch.full((4, 4), float(self.rank), device=dev)
+        got = step("cfg all-gather", lambda: self.cfg_exchange.gather(net))
+        expect(got is not None and got.shape == (8, 4), "cfg all-gather shape")
+        if self.sp is not None:
+            sp, T, pix, C = self.sp, 2 * self.sp.size + 1, 2 * self.sp.size, 8
+            full = torch.arange(T * pix * C, dtype=torch.float32, device=dev).reshape(T * pix, C).to(torch.float16)
+            mine = sp.take_frames(full, 1, T, pix)
+            px = step("all-to-all (frames -> pixels)", lambda: sp.to_pixels(mine, 1, T, pix))
+            if px is None:                              # keep the sequence aligned: the inverse exchange still runs, on a stand-in of the right shape
+                px = torch.zeros((T * sp.pix_local(pix), C), dtype=mine.dtype, device=dev)
+            back = step("all-to-all (pixels -> frames)", lambda: sp.to_frames(px, 1, T, pix))
+            expect(back is not None and torch.equal(back, mine), "all-to-all round trip")
+            gf = step("padded all-gather", lambda: sp.gather_frames(mine, 1, T, pix))
+            expect(gf is not None and torch.equal(gf, full), "padded all-gather")
+            sums = step("fp64 all-reduce", lambda: sp.allreduce_sums(torch.ones((1, 32, 2), dtype=torch.float64, device=dev)))
+            expect(sums is not None and float(sums[0, 0, 0]) == sp.size, "fp64 all-reduce")
+        t = torch.full((3, 5), float(self.rank), device=dev)
+        src = dist.get_global_rank(self.decode_group, 0)
+        step("broadcast", lambda: broadcast(t, src=src, group=self.decode_group))
+        if dev.type == "cuda":
+            step("synchronize", torch.cuda.synchronize)
+        expect(float(t[0, 0]) == float(src), "broadcast")
+        err = "; ".join(errs) if errs else None
         flag = torch.tensor([0.0 if err is None else 1.0], device="cpu" if dist.get_backend() == "gloo" else dev)
         try:
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)

@@ -258,7 +258,7 @@ class StreamingPipeline:
             key_frames = [video[s] for s in starts]                              # 1st frame of every window, enhanced first
             conds = codec.window_conditioning(images, 1, len(key_frames))         # the reference's order of random draws: image latents,
             lat = codec.encode_video(key_frames)                                 # video posterior, SDEdit noise (pipeline_i2vgen_xl.py:784-829)
-            images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng)))   # one window: nothing to shard
+            images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng, group=getattr(self, "group", None))))   # one window: its two CFG halves on two ranks
             video = video[:max_idx]
         else:
             starts, chunk_size, overlap_size = [0], len(video), 0

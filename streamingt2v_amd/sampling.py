@@ -119,7 +119,10 @@ class EulerEDMSampler:
             c2 = {k: half[k].float().contiguous() for k in ("vector", "crossattn", "concat")}
             model_kwargs = dict(model_kwargs, batch_size=1)
         graph = graph_net = None
+        # not under a launch trace / the in-situ tuner: both record timing-enabled events around every launch, which a stream capture refuses
+        # (and a replayed step would emit no records at all)
         graphable = (self.use_graph and x.is_cuda and getattr(wrapper, "sp", None) is None and hasattr(wrapper, "forward_fused_static")
+                     and ops.trace is None and ops.tuner is None
                      and set(model_kwargs) <= {"batch_size", "num_video_frames", "ctrl_frames", "image_only_indicator"})
         for i in range(len(sig) - 1):
             s = float(np.float32(sig[i]))                     # s_in * sigmas[i] is fp32 in the reference

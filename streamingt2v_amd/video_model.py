@@ -157,7 +157,7 @@ class VideoResBlock:
             et_pre = (emb_out[0] if sp is None else emb_out[1])[:, self.et_off:self.et_off + self.cout]
         cv_in = dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F)
         cv = dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F)
-        st = ops.STREAM_F32           # the block's input / intermediate sum / output are the residual stream: fp32 between kernels when set
+        st = ops.stream_on(self.cout, "res")   # the block's intermediate sum / output are the residual stream: fp32 between kernels when set (its input is whatever the block before wrote)
         h = ops.groupnorm(x, F, pix, self.n1w, self.n1b, 1e-5, silu=True)
         e = e_pre if e_pre is not None else ops.gemm(emb_silu, self.we, bias=self.be, out_f32=True)
         h = ops.gemm(h, self.w1, bias=self.b1, rowvec=e, rows_per_vec=pix, conv=cv_in)
@@ -358,7 +358,7 @@ class SpatialVideoTransformer:
         (parallel.SeqParallel) x / ctx hold this rank's frames; the temporal block runs in the pixel layout."""
         c, heads, pix = self.c, self.heads, H * W
         M, B = F * pix, tctx.shape[0]
-        st = ops.STREAM_F32           # fp32 residual stream: x, h, xm are fp32 between the kernels; every GEMM / attention operand is 16 bit
+        st = ops.stream_on(c, "svt")  # fp32 residual stream: h, xm and the output are fp32 between the kernels; every GEMM / attention operand is 16 bit
         e16 = ops.ELEM if x.dtype == torch.float32 else x.dtype
         tctx_tokens = None
         if ctx.dim() == 3:                     # APM: [F, 17, 1024] tokens (fp32); tctx [B, 17, 1024]
@@ -523,9 +523,17 @@ class _EmbedMLP:
     def prepare(self, sd, dev):
         self.w0, self.b0 = _dev_bf16(sd[self.p + "0.weight"], dev), _dev_f32(sd[self.p + "0.bias"], dev)
         self.w2, self.b2 = _dev_bf16(sd[self.p + "2.weight"], dev), _dev_f32(sd[self.p + "2.bias"], dev)
+        # precision plan (ops.EXACT_RIM): the two Linear layers with split-3 operands (a handful of rows per forward: free)
+        self.w0_3 = self.w2_3 = None
+        if ops.EXACT_RIM:
+            self.w0_3, self.w2_3 = pack_x3(sd[self.p + "0.weight"], 1).to(dev), pack_x3(sd[self.p + "2.weight"], 1).to(dev)
 
-    def forward(self, x_bf16, add=None):
-        h = ops.gemm(x_bf16, self.w0, bias=self.b0, silu=True)
+    def forward(self, x, add=None):
+        """x: 16-bit rows, or fp32 rows for the split-3 form (prepared under ops.EXACT_RIM)."""
+        if x.dtype == torch.float32 and self.w0_3 is not None:
+            h = ops.gemm(ops.rows_split3(x), self.w0_3, bias=self.b0, silu=True, out_f32=True)
+            return ops.gemm(ops.rows_split3(h), self.w2_3, bias=self.b2, rowvec=add, rows_per_vec=1, out_f32=True)
+        h = ops.gemm(ops.to_elem_rows(x), self.w0, bias=self.b0, silu=True)
         return ops.gemm(h, self.w2, bias=self.b2, rowvec=add, rows_per_vec=1, out_f32=True)
 
 
@@ -607,9 +615,12 @@ class _EncoderBase:
         self._enc_ch, self._enc_ds = ch, ds
 
     def _embed(self, timesteps, y):
-        t_emb = ops.timestep_embedding(timesteps, self.mc)
-        emb = self.time_embed.forward(t_emb)
-        emb = self.label_emb.forward(ops.to_bf16(y), add=emb)      # emb + label_emb(y)
+        if self.time_embed.w0_3 is not None:                        # precision plan: fp32 in, split-3 operands (see _EmbedMLP.prepare)
+            emb = self.time_embed.forward(ops.timestep_embedding(timesteps, self.mc, f32=True))
+            emb = self.label_emb.forward(y, add=emb)
+        else:
+            emb = self.time_embed.forward(ops.timestep_embedding(timesteps, self.mc))
+            emb = self.label_emb.forward(ops.to_bf16(y), add=emb)  # emb + label_emb(y)
         return ops.to_bf16(emb, silu=True)                          # every emb_layers starts with SiLU
 
     def _pack_emb_layers(self):
@@ -635,7 +646,7 @@ class _EncoderBase:
             elif isinstance(m, SpatialVideoTransformer):
                 h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp)
             else:
-                h, H, W = m.forward(h, F, H, W, out_f32=ops.STREAM_F32)      # stem / Downsample / Upsample convolutions write the stream
+                h, H, W = m.forward(h, F, H, W, out_f32=ops.stream_on(m.cout))      # stem / Downsample / Upsample convolutions write the stream
         return h, H, W
 
     def _local_conditioning(self, timesteps, context, y, T, sp):

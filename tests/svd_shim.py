@@ -261,12 +261,12 @@ def to_elem(x, silu=False):
     return (F.silu(x) if silu else x).to(ops.ELEM)
 
 
-def timestep_embedding(t, dim, max_period=10000.0):
+def timestep_embedding(t, dim, max_period=10000.0, f32=False):
     from streamingt2v_amd import ops
     half = dim // 2
     freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t[:, None].float() * freqs[None]
-    return torch.cat([torch.cos(args), torch.sin(args)], -1).to(ops.ELEM)
+    return torch.cat([torch.cos(args), torch.sin(args)], -1).to(torch.float32 if f32 else ops.ELEM)
 
 
 def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):

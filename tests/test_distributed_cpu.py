@@ -193,6 +193,51 @@ def _sp_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+# ---- enhancement stage: (window, CFG half) units sharded over the ranks (blending.blend_step_units_sharded) ---------------------------------
+def _ph(idx, half, w):                      # stand-in for one CFG half of the UNet evaluation of a window: [B, C, chunk, H, W] -> [chunk, C, H, W]
+    return (w[0].permute(1, 0, 2, 3) * (1.0 + 0.25 * half) + 0.125 * idx).contiguous()
+
+
+def _cb(idx, w, pu, pc):                    # stand-in for guidance + scheduler step
+    return (w[0].permute(1, 0, 2, 3) - 0.5 * (pu + 9.0 * (pc - pu))).permute(1, 0, 2, 3)[None]
+
+
+def _units_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from streamingt2v_amd import parallel
+    from streamingt2v_amd.blending import blend_step, blend_step_units_sharded
+    assert parallel.init_from_env(backend="gloo") == world
+    try:
+        lat, cs, ov, n = _case()
+        ok = True
+        for nn, ll, c, o in ((n, lat, cs, ov), (1, lat[:, :, :38], 38, 0), (5, torch.arange(1 * 2 * 46 * 2 * 2, dtype=torch.float32).reshape(1, 2, 46, 2, 2), 14, 6)):
+            ref = blend_step(ll, lambda idx, w: _cb(idx, w, _ph(idx, 0, w), _ph(idx, 1, w)), c, o, nn, random.Random(33))
+            got = blend_step_units_sharded(ll, _ph, _cb, c, o, nn, random.Random(33))
+            ok = ok and torch.equal(ref, got)
+        parallel.barrier()
+        out.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_enhancer_units_sharded_equals_single_process(world):
+    """3 windows x 2 CFG halves = 6 units on 2 / 3 / 8 ranks (8: two ranks hold no unit and still join the all-gather); the 1-window key-frame
+    pre-pass (2 units) and a 5-window case with padded slots: bit-identical latents on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_units_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r for r, _ in res] == list(range(world)) and all(ok for _, ok in res), res
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sequence_parallel_forward_equals_single_process(world):
     """The frame <-> pixel sequence-parallel StreamingWrapper forward (all-to-all around the temporal operators, all-reduced 5-D

@@ -42,7 +42,7 @@ def check(name, got, ref, atol, rtol):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 26])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 320, 320), (77, 960, 64), (4096, 640, 1280)])
 def test_gemm_plain(ops, cfg, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
@@ -81,12 +81,12 @@ def test_gemm_epilogues(ops):
     check("gemm silu", out, F.silu(a.float() @ w.float().t() + bias), 2e-2, 1e-2)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 8, 17, 19, 20, 21, 22, 23, 24, 26])
+@pytest.mark.parametrize("cfg", [1, 2, 8, 17, 19, 20, 21, 22, 23])
 @pytest.mark.parametrize("K", [32, 128, 704])
 def test_gemm_many_tiles_per_workgroup(ops, cfg, K, M=33000):
     """More tiles than resident workgroups: exercises the persistent loop (tile prologue requested before the previous tile's epilogue,
     the static / dynamic vmcnt waits for 2-, 3- and 4-stage rings) and the aux-slot ring; K shorter / longer than the ring."""
-    if K % 64 and cfg not in (17, 19, 23, 24, 26):
+    if K % 64 and cfg not in (17, 19, 23):
         pytest.skip("config needs K % 64 == 0")
     N, rpv = 512, 1000
     a, w = rnd(M, K, seed=30), rnd(N, K, scale=K ** -0.5, seed=31)
@@ -103,7 +103,7 @@ def test_gemm_many_tiles_per_workgroup(ops, cfg, K, M=33000):
     check(f"many tiles cfg{cfg} K{K} f32", out, mm, 2e-3, 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 9, 10, 11, 12, 17, 18, 19, 20, 23, 26])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 9, 10, 11, 12, 17, 18, 19, 20, 23])
 def test_gemm_geglu(ops, cfg):
     from streamingt2v_amd.video_model import pack_geglu
     M, C = 300, 320
@@ -134,7 +134,7 @@ def test_gemm_conv3x3(ops, stride, ups, cin, cout, H, W):
     check(f"conv3x3 s{stride} u{ups} {cin}->{cout}", out, ref.permute(0, 2, 3, 1).reshape(-1, cout), 3e-2, 1e-2)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 8, 19, 20, 21, 22, 23, 24, 26])
+@pytest.mark.parametrize("cfg", [1, 2, 8, 19, 20, 21, 22, 23])
 def test_gemm_implicit_views_many_tiles(ops, cfg):
     """conv3x3 / temporal implicit GEMMs with more tiles than resident workgroups, per tile configuration
     (persistent loop across tiles) + residual + per-frame vector."""
@@ -337,7 +337,7 @@ def test_rows_split3(ops, C):
     ref = F.silu(F.layer_norm(x, (C,), g, b, 1e-5))
     err = (_join3(s3, C) - ref).abs().max().item()
     print(f"[rows_split3 C{C} LN + SiLU] max abs err {err:.3e}")
-    assert err <= 2e-5
+    assert err <= (2e-4 if BF16 == torch.bfloat16 else 5e-6)          # hi + lo: 16 significant bits in bf16, 22 in fp16
 
 
 @pytest.mark.parametrize("cin,cout,stride,H,W", [(3, 32, 1, 24, 40), (32, 96, 2, 24, 40), (96, 96, 1, 12, 20), (256, 512, 2, 12, 20), (8, 320, 1, 9, 16)])

@@ -136,3 +136,67 @@ def test_job_plan_on_hip_kernels_multi_process(world):
         assert d["pairs_bit_identical"] and d["pairs_decode_identical"] and d["pairs_videos"] == (world // 2, d["rank"] // 2), d
     # every rank of a run ends with the same state (the collectives deliver identical bits everywhere)
     assert len({round(d["e_job"], 12) for d in res}) == 1
+
+
+# ---- enhancement stage: (window, CFG half) units over the ranks, on the HIP kernels --------------------------------------------------------------
+def _enh_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    torch.set_grad_enabled(False)
+    from oracle import cases
+    from streamingt2v_amd import parallel
+    from streamingt2v_amd.enhance import DDIMSchedule, I2VEnhancer
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from streamingt2v_amd.params import init_by_name
+    assert parallel.init_from_env(backend="gloo") == world
+    try:
+        kw, ti = cases.tiny_i2v_kwargs(), cases.TINY_I2V
+        unet = I2VGenXLUNet(I2VConfig(block_out_channels=kw["block_out_channels"], layers_per_block=kw["layers_per_block"],
+                                      cross_attention_dim=kw["cross_attention_dim"], attn_levels=(True, True, False)))
+        unet.load_state_dict(init_by_name(unet.spec(), seed=5), device="cuda")
+        chunk, overlap, Hh, Ww, cd = ti["F"], 2, ti["h"], ti["w"], ti["cross_attention_dim"]
+        n_win = 3
+        n_frames = n_win * chunk - (n_win - 1) * overlap
+        g = torch.Generator(); g.manual_seed(2024)
+        video, noise = torch.randn(1, 4, n_frames, Hh, Ww, generator=g) * 0.5, torch.randn(1, 4, n_frames, Hh, Ww, generator=g)
+        conds = []
+        for _ in range(n_win):
+            il = torch.randn(1, 4, chunk, Hh, Ww, generator=g) * 0.7
+            emb, text = torch.randn(1, cd, generator=g), torch.randn(1, ti["text_tokens"], cd, generator=g)
+            conds.append(dict(fps=torch.tensor([8, 8]), image_latents=torch.cat([il, il]), image_embeddings=torch.cat([torch.zeros_like(emb), emb]),
+                              text=torch.cat([torch.zeros_like(text), text])))
+        enh = I2VEnhancer(unet, DDIMSchedule(), guidance_scale=9.0, num_inference_steps=10, strength=0.35)       # 3 DDIM steps
+        one = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33))
+        units = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33), group=dist.group.WORLD)
+        wins = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33), group=dist.group.WORLD, shard="windows")
+        torch.cuda.synchronize()
+        out.put(dict(rank=rank, units_identical=bool(torch.equal(one, units)), windows_identical=bool(torch.equal(one, wins)), e_units=_rel(units, one)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_enhancer_cfg_half_units_on_hip_kernels_multi_process(world):
+    """3 blending windows x 2 CFG halves = 6 units over 2 / 4 ranks (4: two ranks get two units, two get one): the sharded SDEdit loop (3 DDIM
+    steps, randomized blending, guidance 9) equals the single-process loop BIT FOR BIT -- a CFG half evaluated alone (batch 1) equals its half of
+    the batched evaluation (per-sample GroupNorm statistics and attention), the all-gather and the replicated guidance + DDIM kernel add nothing.
+    Reference loop being sharded: code/i2v_enhance/pipeline_i2vgen_xl.py:841-913."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_enh_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for d in res:
+        print(f"[enhancer units sharded, world {world}, rank {d['rank']}] vs single process: units bit-identical {d['units_identical']} "
+              f"(relative L2 {d['e_units']:.2e}), whole windows bit-identical {d['windows_identical']}")
+        assert d["windows_identical"], d
+        assert d["units_identical"], d

@@ -43,9 +43,13 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
     prev_stream = ops.STREAM_F32
     if stream_f32 is not None:
         ops.set_stream_f32(stream_f32)
-    prev_plan = (ops.EXACT_RIM, ops.CN_STREAM_F32)
-    if plan is not None:              # (exact_rim, cn_stream_f32): the round-4 precision plan (None = the package default)
-        ops.set_precision_plan(*plan)
+    prev_plan = (ops.EXACT_RIM, ops.CN_STREAM_F32, ops.STREAM_F32_MIN_CH)
+    prev_kind = dict(ops.STREAM_F32_MIN_CH_KIND)
+    if plan is not None:              # (exact_rim, cn_stream_f32, stream_f32_min_ch[, per-kind thresholds]): the round-4 precision plan (None = the package default)
+        ops.set_precision_plan(*plan[:3])
+        ops.STREAM_F32_MIN_CH_KIND.update({"res": None, "svt": None})
+        if len(plan) > 3:
+            ops.STREAM_F32_MIN_CH_KIND.update(plan[3])
     gold = torch.load(os.path.join(GOLD, "wrapper_fullsize.pt"))
     cfg = UNetConfig()
     unet, cn = VideoUNet(cfg), ControlNet(cfg)
@@ -63,7 +67,7 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
     torch.cuda.synchronize()
     res = frame_errors(out, gold["out"])
     res["stream_f32"] = ops.STREAM_F32
-    res["plan"] = (ops.EXACT_RIM, ops.CN_STREAM_F32)
+    res["plan"] = (ops.EXACT_RIM, ops.CN_STREAM_F32, ops.STREAM_F32_MIN_CH, {k: v for k, v in ops.STREAM_F32_MIN_CH_KIND.items() if v is not None})
     if timing:
         import time
         t0 = time.perf_counter()
@@ -74,6 +78,7 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
         res["ms"] = (time.perf_counter() - t0) / 3 * 1e3
     ops.set_stream_f32(prev_stream)
     ops.set_precision_plan(*prev_plan)
+    ops.STREAM_F32_MIN_CH_KIND.update(prev_kind)
     del unet, cn, wrap
     torch.cuda.empty_cache()
     return res
@@ -106,9 +111,11 @@ def main():
     ap.add_argument("--which", default="both")
     ap.add_argument("--stream", default="default", choices=["default", "fp32", "16", "both"], help="residual stream of the wrapper: fp32 / 16 bit / both")
     ap.add_argument("--timing", action="store_true")
-    ap.add_argument("--plans", default="default", help="'default' or 'sweep': every (exact rim, fp32 stream inside the ControlNet) combination of the round-4 precision plan")
+    ap.add_argument("--plans", default="default", help="'default' or 'sweep': the round-4 precision plan off / rim + ControlNet stream / + the UNet's fp32 stream at >= 1280, 640, 320 channels")
     a = ap.parse_args()
-    plans = [None] if a.plans == "default" else [(False, False), (True, False), (False, True), (True, True)]
+    plans = [None] if a.plans == "default" else [(False, False, 0), (True, True, 0), (True, True, 1280), (True, True, 640), (True, True, 320)]
+    if a.plans == "level0":           # which KIND of level-0 block needs the fp32 stream: (rim, ControlNet stream, UNet >= 640) + ResBlocks / transformers at 320
+        plans = [(True, True, 640, {"res": 320}), (True, True, 640, {"svt": 320}), (True, True, 320)]
     sds = {}
     for name in ("fp16", "bf16"):
         if a.dtype not in ("both", name):
@@ -121,7 +128,7 @@ def main():
             for st, plan in [(st, pl) for st in {"default": [None], "fp32": [True], "16": [False], "both": [True, False]}[a.stream] for pl in plans]:
                 r = wrapper_fullsize(name, sds=sds, stream_f32=st, timing=a.timing, plan=plan)
                 print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, {name}, residual stream {'fp32' if r['stream_f32'] else '16 bit'}, "
-                      f"exact rim {'on' if r['plan'][0] else 'off'}, ControlNet stream {'fp32' if r['plan'][1] else '16 bit'}] "
+                      f"exact rim {'on' if r['plan'][0] else 'off'}, ControlNet stream {'fp32' if r['plan'][1] else '16 bit'}, UNet fp32 stream at >= {r['plan'][2] or 'inf'} channels{(' ' + str(r['plan'][3])) if r['plan'][3] else ''}] "
                       f"per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | "
                       f"corr {r['corr']:.7f}" + (f" | forward {r['ms']:.1f} ms" if "ms" in r else ""), flush=True)
 

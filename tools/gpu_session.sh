@@ -2,7 +2,7 @@
 # One parametrised lease script (round 4; replaces the per-call r3*.sh files):  gpurun -- 'bash tools/gpu_session.sh <out-dir> <step> [<step> ...]'
 # Every step writes under gpurun_out/<out-dir>/ and is bounded by its own timeout.  Steps:
 #   kernels     kernel-level GPU tests (GEMM tiles, norms)                norms       tools/norm_bench.py, packed / one-row LayerNorm and fused / separate GroupNorm finalize
-#   tune2wg     tools/tune_gemm.py --only ar16 for three start de-phasing spans of the two-per-CU tiles
+#   tunear      tools/tune_gemm.py --only ar16 (A/B of kernel variants)      paritysweep   A5 at full size over the precision plans      bench6ab   bench6 with the plan off / default / without the UNet's part
 #   tune        the full tuner (writes streamingt2v_amd/gemm_tiles.json, copied out)
 #   spbisect    tools/sp_delta_bisect.py                                   bench6      bench.py --steps 6 --warmup 1 (no trace / CPU baseline)
 #   bench       the driver's command (bench.py --steps 20 --warmup 5)      parity      tools/fullsize_parity.py (A5 at full size vs the reference golden)
@@ -13,14 +13,20 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
 for step in "$@"; do
   echo "== $step"; t0=$(date +%s)
   case $step in
-    kernels)  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "gemm_plain or many_tiles or geglu or implicit_views or groupnorm or layernorm" > $O/kernels.log 2>&1; tail -3 $O/kernels.log ;;
-    norms)    SVD_LN_PACKED=0 SVD_GN_FUSED_FINALIZE=0 timeout 200 python tools/norm_bench.py > $O/norm_bandwidth_before.txt 2>$O/norm_before.err
-              timeout 200 python tools/norm_bench.py > $O/norm_bandwidth_after.txt 2>$O/norm_after.err
-              grep -h "layernorm\|gn_stats" $O/norm_bandwidth_before.txt | head -12; echo --; grep -h "layernorm\|gn_stats" $O/norm_bandwidth_after.txt | head -12 ;;
-    tune2wg)  for sp in 0 8 16; do SVD_GEMM_DEPHASE_2WG=$sp timeout 300 python tools/tune_gemm.py --only ar16 --out $O/tiles_span$sp.json > $O/tune_span$sp.log 2>$O/tune_span$sp.err; tail -2 $O/tune_span$sp.log | head -1; done ;;
+    kernels)  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -s -p no:cacheprovider -k "gemm_plain or many_tiles or geglu or implicit_views or groupnorm or layernorm or split3 or x3 or head" > $O/kernels.log 2>&1; grep -E "^\[(rows_split3|x3 conv|head)" $O/kernels.log | head -40; tail -3 $O/kernels.log ;;
+    tunear)   timeout 300 python tools/tune_gemm.py --only ar16 --out $O/tiles_ar16.json > $O/tune_ar16.log 2>$O/tune_ar16.err; tail -3 $O/tune_ar16.log ;;
+    newtests) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_multiproc.py tests/test_gpu_fullsize.py tests/test_gpu_graph.py -m gpu -q -x -s -p no:cacheprovider > $O/newtests.log 2>&1; grep -E "^\[" $O/newtests.log | grep -v Gloo | cut -c1-260 | head -40; tail -3 $O/newtests.log ;;
+    paritylevel0) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --plans level0 --timing > $O/fullsize_parity_level0.txt 2>$O/parity_level0.err; cat $O/fullsize_parity_level0.txt ;;
+    paritysweep) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --plans sweep --timing > $O/fullsize_parity_sweep.txt 2>$O/parity_sweep.err; cat $O/fullsize_parity_sweep.txt; tail -3 $O/parity_sweep.err ;;
+    norms)    timeout 200 python tools/norm_bench.py > $O/norm_bandwidth_after.txt 2>$O/norm_after.err
+              grep -h "layernorm\|gn_stats" $O/norm_bandwidth_after.txt | head -12 ;;
     tune)     timeout 400 python tools/tune_gemm.py > $O/tune.log 2>$O/tune.err; cp streamingt2v_amd/gemm_tiles.json $O/gemm_tiles.json; head -8 $O/tune.log ;;
     spbisect) timeout 400 python tools/sp_delta_bisect.py > $O/sp_delta_bisect.txt 2>$O/spbisect.err; tail -4 $O/sp_delta_bisect.txt; tail -3 $O/spbisect.err ;;
     bench6)   timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6.json 2>$O/bench6.err; cut -c1-420 $O/bench6.json ;;
+    bench6ab) SVD_EXACT_RIM=0 SVD_CN_STREAM_F32=0 SVD_STREAM_F32_MIN_CH=0 timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_plan_off.json 2>$O/bench6_off.err
+              timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_plan_default.json 2>$O/bench6_def.err
+              SVD_STREAM_F32_MIN_CH=0 timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_plan_rim_cn.json 2>$O/bench6_rc.err
+              for f in $O/bench6_plan_*.json; do echo $f; cut -c50-75 $f; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $f; done ;;
     bench)    timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_stage1.json 2>$O/bench.err; cut -c1-420 $O/bench_stage1.json ;;
     parity)   timeout 600 python tools/fullsize_parity.py > $O/fullsize_parity.txt 2>$O/parity.err; tail -12 $O/fullsize_parity.txt ;;
     profile)  (cd /tmp && export TMPDIR=/tmp && SVD_WORKLOG=$O/wl.json timeout 500 rocprofv3 --kernel-trace --stats -d $O/prof_rt -o rt -- python $R/bench.py --workload ar_chunk --steps 2 --warmup 1 --no-trace --no-cpu-baseline > $O/rt_bench.log 2>&1)

@@ -76,7 +76,8 @@ def main():
     # both residual-stream forms of the UNet / ControlNet: their producers are different kernels (fp32 stream: `_o1` signatures)
     plans = (("ar_chunk", True), ("c2", True), ("ar_chunk", False), ("c2", False)) if a.only != "ar16" else (("ar_chunk", False),)
     for workload, stream in plans:
-        ops.set_stream_f32(stream)
+        ops.set_stream_f32(stream)                      # True: every block's stream in fp32 (= the round-4 default plan); False: the all-16-bit plan
+        ops.set_precision_plan(exact_rim=True, cn_stream_f32=stream, stream_f32_min_ch=320 if stream else 0)
         wrapper, vae = bench.build_models(workload, dev)
         from streamingt2v_amd.sampling import EulerEDMSampler
         from streamingt2v_amd.streaming_svd import StreamingSVD
@@ -88,7 +89,8 @@ def main():
         print(f"{workload} (residual stream {'fp32' if stream else '16 bit'}): {len(tuner.table)} signatures after {time.time() - t0:.0f}s", flush=True)
         del wrapper, vae, model
         torch.cuda.empty_cache()
-    ops.set_stream_f32(True)
+    ops.set_stream_f32(False)
+    ops.set_precision_plan(exact_rim=True, cn_stream_f32=True, stream_f32_min_ch=320)
     if a.only != "ar16":
         # enhancement stage: one I2VGen-XL UNet forward of a 38-frame window (CFG batch 2) at latent 90x160
         from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
