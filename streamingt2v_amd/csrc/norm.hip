@@ -503,10 +503,12 @@ extern "C" int svd_groupnorm(const void* X, int64_t ldx, svd_bf16* Y, int64_t ld
         if (rc != SVD_OK) return rc;
         return svd_groupnorm_apply(X, ldx, Y, ldy, frames, pix, channels, groups, frames_per_stat, stats, gamma, beta, silu, dtype, stream);
     }
+    const float count = (float)frames_per_stat * (float)pix * (float)(channels / groups);
+    // (Running the two passes in frame batches sized for the 256-MiB Infinity Cache, last-written frames first, was measured and is slower at every
+    // batch size: profiles/r04_groupnorm_frame_batches.txt.)
     SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_stats_partial_kernel<E, IN32>), dim3(nchunk, frames), dim3(bs), (size_t)(bs / (channels >> 3)) * 2 * channels * sizeof(float),
                                               (hipStream_t)stream, X, ldx, pix, channels, groups, nchunk, partial));
     SVD_CHECK_LAUNCH("gn_stats_partial");
-    const float count = (float)frames_per_stat * (float)pix * (float)(channels / groups);
     SVD_DISPATCH_IN(dtype, hipLaunchKernelGGL((gn_apply_kernel<E, IN32, true>), dim3(nchunk, frames), dim3(bs), 0, (hipStream_t)stream, X, ldx, Y, ldy,
                                               pix, channels, groups, frames_per_stat, nchunk, partial, gamma, beta, silu, count, eps));
     SVD_CHECK_LAUNCH("gn_apply_fin");

@@ -76,6 +76,11 @@ def set_precision_plan(exact_rim=None, cn_stream_f32=None, stream_f32_min_ch=Non
         STREAM_F32_MIN_CH = int(stream_f32_min_ch)
 
 
+# transformers below their own threshold but at / above this one keep only their BLOCK OUTPUT (x + proj_out(...), the tensor the next block's residual
+# chain starts from) in fp32: one extra 4-byte tensor per block instead of seven (A/B sweeps; 0 = off)
+STREAM_F32_SVT_IO_MIN_CH = int(_os.environ.get("SVD_STREAM_F32_SVT_IO_MIN_CH", "0"))
+
+
 def stream_on(channels, kind=None):
     """Does a block of `channels` channels keep its residual stream in fp32?  (STREAM_F32: every block; else the precision plan's threshold.)"""
     if STREAM_F32:

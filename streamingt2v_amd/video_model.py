@@ -416,7 +416,8 @@ class SpatialVideoTransformer:
         if sp is not None:
             xb = sp.to_frames(xb, B, T, pix)                                                    # one all-to-all out
         # xb (the blend) is consumed by proj_out only: a GEMM operand, 16 bit; proj_out + x continues the stream
-        return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out_f32=st)
+        out32 = st or (ops.STREAM_F32_SVT_IO_MIN_CH > 0 and c >= ops.STREAM_F32_SVT_IO_MIN_CH)      # (A/B) block output alone in fp32
+        return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out_f32=out32)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -48,8 +48,11 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
     if plan is not None:              # (exact_rim, cn_stream_f32, stream_f32_min_ch[, per-kind thresholds]): the round-4 precision plan (None = the package default)
         ops.set_precision_plan(*plan[:3])
         ops.STREAM_F32_MIN_CH_KIND.update({"res": None, "svt": None})
+        ops.STREAM_F32_SVT_IO_MIN_CH = 0
         if len(plan) > 3:
-            ops.STREAM_F32_MIN_CH_KIND.update(plan[3])
+            kinds = dict(plan[3])
+            ops.STREAM_F32_SVT_IO_MIN_CH = kinds.pop("svt_io", 0)
+            ops.STREAM_F32_MIN_CH_KIND.update(kinds)
     gold = torch.load(os.path.join(GOLD, "wrapper_fullsize.pt"))
     cfg = UNetConfig()
     unet, cn = VideoUNet(cfg), ControlNet(cfg)
@@ -67,7 +70,8 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
     torch.cuda.synchronize()
     res = frame_errors(out, gold["out"])
     res["stream_f32"] = ops.STREAM_F32
-    res["plan"] = (ops.EXACT_RIM, ops.CN_STREAM_F32, ops.STREAM_F32_MIN_CH, {k: v for k, v in ops.STREAM_F32_MIN_CH_KIND.items() if v is not None})
+    res["plan"] = (ops.EXACT_RIM, ops.CN_STREAM_F32, ops.STREAM_F32_MIN_CH, dict({k: v for k, v in ops.STREAM_F32_MIN_CH_KIND.items() if v is not None},
+                                                                                 **({"svt_io": ops.STREAM_F32_SVT_IO_MIN_CH} if ops.STREAM_F32_SVT_IO_MIN_CH else {})))
     if timing:
         import time
         t0 = time.perf_counter()
@@ -79,6 +83,7 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
     ops.set_stream_f32(prev_stream)
     ops.set_precision_plan(*prev_plan)
     ops.STREAM_F32_MIN_CH_KIND.update(prev_kind)
+    ops.STREAM_F32_SVT_IO_MIN_CH = 0
     del unet, cn, wrap
     torch.cuda.empty_cache()
     return res
@@ -116,6 +121,8 @@ def main():
     plans = [None] if a.plans == "default" else [(False, False, 0), (True, True, 0), (True, True, 1280), (True, True, 640), (True, True, 320)]
     if a.plans == "level0":           # which KIND of level-0 block needs the fp32 stream: (rim, ControlNet stream, UNet >= 640) + ResBlocks / transformers at 320
         plans = [(True, True, 640, {"res": 320}), (True, True, 640, {"svt": 320}), (True, True, 320)]
+    if a.plans == "level0io":         # level-0 ResBlocks in fp32 + the level-0 transformers' block output alone
+        plans = [(True, True, 640, {"res": 320, "svt_io": 320}), (True, True, 320)]
     sds = {}
     for name in ("fp16", "bf16"):
         if a.dtype not in ("both", name):

@@ -16,6 +16,7 @@ for step in "$@"; do
     kernels)  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -s -p no:cacheprovider -k "gemm_plain or many_tiles or geglu or implicit_views or groupnorm or layernorm or split3 or x3 or head" > $O/kernels.log 2>&1; grep -E "^\[(rows_split3|x3 conv|head)" $O/kernels.log | head -40; tail -3 $O/kernels.log ;;
     tunear)   timeout 300 python tools/tune_gemm.py --only ar16 --out $O/tiles_ar16.json > $O/tune_ar16.log 2>$O/tune_ar16.err; tail -3 $O/tune_ar16.log ;;
     newtests) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_multiproc.py tests/test_gpu_fullsize.py tests/test_gpu_graph.py -m gpu -q -x -s -p no:cacheprovider > $O/newtests.log 2>&1; grep -E "^\[" $O/newtests.log | grep -v Gloo | cut -c1-260 | head -40; tail -3 $O/newtests.log ;;
+    paritylevel0io) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --plans level0io --timing > $O/fullsize_parity_level0io.txt 2>$O/parity_level0io.err; cat $O/fullsize_parity_level0io.txt ;;
     paritylevel0) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --plans level0 --timing > $O/fullsize_parity_level0.txt 2>$O/parity_level0.err; cat $O/fullsize_parity_level0.txt ;;
     paritysweep) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --plans sweep --timing > $O/fullsize_parity_sweep.txt 2>$O/parity_sweep.err; cat $O/fullsize_parity_sweep.txt; tail -3 $O/parity_sweep.err ;;
     norms)    timeout 200 python tools/norm_bench.py > $O/norm_bandwidth_after.txt 2>$O/norm_after.err

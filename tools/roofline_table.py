@@ -62,6 +62,8 @@ def main(db, wl_path, out=None):
             b = base_name(name)
             key = "attn_temporal" if b.startswith("attn_temporal") else b
             label = b
+            if b in ("layernorm_kernel", "layernorm_packed_kernel"):          # one work-log entry (ops.layernorm) covers both forms of the kernel
+                key, label = "layernorm_kernel", "layernorm_kernel + layernorm_packed_kernel"
         else:
             _, i, amode, el = key.split("|")
             c = cfgs[int(i)]
