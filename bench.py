@@ -554,6 +554,7 @@ def run_full(args, rank, world, device):
     assert n_final == 2 * n_enh and out.shape[1:] == (720, 1280, 3) and str(out.dtype) == "uint8", (out.shape, out.dtype, n_enh)
     # roofline of the job's dominant kernel: ONE more job with HIP events around every GEMM / MFMA-attention launch of all three stages (the timed
     # region above is untraced); the GEMM family is one kernel template across stage 1, the enhancer, both VAEs and EMA-VFI.
+    stage_mean = {k: round(v / args.steps, 2) for k, v in stage_s.items()}          # of the TIMED jobs (the traced job below would add to stage_s)
     roof = None
     if not args.no_trace and world == 1:
         from streamingt2v_amd import ops
@@ -581,7 +582,7 @@ def run_full(args, rank, world, device):
             "config": {"workload": "full pipeline (BASELINE configs[4]; inference_i2v.py:227-259): stage 1 (100 frames @576x1024) + I2VGen-XL enhancement with "
                                    "randomized blending (3 windows x 38 frames, overlap 12, key-frame pre-pass, %d DDIM steps, CFG 9, 2-D VAE encode/decode @720x1280) "
                                    "+ EMA-VFI to 200 frames" % len(pipe_timesteps(pipe)),
-                       "seconds_per_job": {k: round(v / args.steps, 2) for k, v in stage_s.items()}, "frames_after_enhancement": int(n_enh),
+                       "seconds_per_job": stage_mean, "frames_after_enhancement": int(n_enh),
                        "final_frames_per_job": int(n_final),
                        "parallelism": {"stage1": plan.describe(),
                                        "enhance": ("6 (window, CFG half) units + the key-frame pre-pass's 2 over the ranks of the video's group, one all-gather per DDIM step"
