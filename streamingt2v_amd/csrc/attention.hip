@@ -223,6 +223,170 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_d64_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Round-4 experiment (SVD_ATTN_PIPE=1, 8-wave workgroups only): the SAME arithmetic with the S^T MFMAs of KV tile t+1 issued BEFORE the softmax of
+// tile t inside a wave, so that a wave's own matrix work runs under its own softmax VALU (the round-3 review's untried variant).  That needs a second
+// score accumulator (32 registers): 2 waves per SIMD with up to 256 VGPRs instead of 4 with 128, a ring of THREE K / V^T buffers (tile t+2 is requested
+// while t+1 is multiplied and t is normalised) and sched_group_barrier to interleave the 8 MFMAs with the VALU stream in program order (the wave
+// issues in order: MFMAs placed first would stall the VALU behind their dependent chain).
+// ------------------------------------------------------------------------------------------------------------
+template <class E>
+__global__ __launch_bounds__(512, 2) void attn_spatial_pipe_kernel(
+    const svd_bf16* __restrict__ Q, int64_t ldq, const svd_bf16* __restrict__ K, int64_t ldk,
+    const svd_bf16* __restrict__ Vt, int64_t tok_ld, svd_bf16* __restrict__ O, int64_t ldo,
+    int frames, int n_q, int n_tok /* keys */, int kv_div, int heads, int qblocks) {
+    constexpr int NW = 8, NT = NW * 64, BQ = NW * 32, KT = 64, TILE_B = KT * 128, BUF_B = 2 * TILE_B, NBUF = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF buffers of (K tile + Vt tile)
+    const uint32_t smem_base = lds_addr_of(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int fh = wgid / qblocks, qb = wgid - fh * qblocks;
+    const int f = fh / heads, h = fh - f * heads;
+    const int fkv = f / kv_div;
+    const svd_bf16* Qf = Q + (int64_t)f * n_q * ldq + h * 64;
+    const svd_bf16* Kf = K + (int64_t)fkv * n_tok * ldk + h * 64;
+    const svd_bf16* Vf = Vt + ((int64_t)fkv * heads + h) * 64 * tok_ld;
+    int qrow = qb * BQ + wave * 32 + l31;
+    const bool q_valid = qrow < n_q;
+    if (!q_valid) qrow = n_q - 1;
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(Qf + (int64_t)qrow * ldq + 16 * ks + 8 * hi);
+    const int srow = tid >> 3, ps = tid & 7;          // NT / 8 = 64 rows per pass: one pass per tile
+    const int ls = ps ^ ((srow >> 1) & 7);
+    auto stage = [&](int t, int buf) {
+        const int kv0 = t * KT;
+        const uint32_t dK = __builtin_amdgcn_readfirstlane(smem_base + buf * BUF_B + wave * 1024);
+        const int r = srow;
+        const int kperm = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+        int key = kv0 + kperm;
+        if (key > n_tok - 1) key = n_tok - 1;
+        glds16_asm(Kf + (int64_t)key * ldk + ls * 8, dK);
+        glds16_asm(Vf + (int64_t)r * tok_ld + kv0 + ls * 8, dK + TILE_B);
+    };
+    auto scores = [&](int buf, f32x16_t (&s_acc)[2]) __attribute__((always_inline)) {
+        const char* sK = smem + buf * BUF_B;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s_acc[0][i] = 0.f; s_acc[1][i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int lslot = 2 * ks + hi;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int row = kb * 32 + l31;
+                const uint4 kf = *(const uint4*)(sK + row * 128 + ((lslot ^ ((row >> 1) & 7)) << 4));
+                s_acc[kb] = E::mfma(kf, qf[ks], s_acc[kb]);
+            }
+        }
+    };
+    f32x16_t o_acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o_acc[0][i] = 0.f; o_acc[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = 0.125f * 1.44269504088896341f;
+    const int ntiles = (n_tok + KT - 1) / KT;
+    stage(0, 0);
+    if (ntiles > 1) stage(1, 1);
+    svd_wait_dma();
+    __syncthreads();
+    f32x16_t s_a[2], s_b[2];
+    scores(0, s_a);
+    int bcur = 0;                                      // buffer of tile t
+    // one KV tile: `sc` holds S^T of tile t (computed one iteration earlier), `sn` receives S^T of tile t+1.  The two accumulator sets swap roles
+    // every tile (the loop below is unrolled by two) instead of being copied.
+    auto tile = [&](int t, f32x16_t (&sc)[2], f32x16_t (&sn)[2]) __attribute__((always_inline)) {
+        const int bnxt = bcur + 1 == NBUF ? 0 : bcur + 1, bnn = bnxt + 1 == NBUF ? 0 : bnxt + 1;
+        if (t + 2 < ntiles) stage(t + 2, bnn);          // the buffer of tile t-1: every wave is past the barrier that ended iteration t-1
+        const int kv0 = t * KT;
+        if (kv0 + KT > n_tok) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * kb + (r & 7) + 8 * hi + 16 * (r >> 3);
+                    if (key >= n_tok) sc[kb][r] = -INFINITY;
+                }
+        }
+        // ---- S^T of tile t+1 (MFMA) interleaved with the softmax of tile t (VALU).  Unconditional: after the last tile the buffer holds stale but
+        //      valid data and the result is never used -- a branch here would put the MFMAs in their own basic block, out of the scheduler's reach.
+        float mx = sc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const bool rescale = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;
+        m_run = m_new;
+        if (rescale) {          // (before the MFMAs of this tile: the compiler hoists this branch here anyway -- it only needs the row maximum)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o_acc[0][i] *= alpha; o_acc[1][i] *= alpha; }
+        }
+        scores(bnxt, sn);       // same basic block as the exponentials below: the scheduler interleaves these independent MFMAs with them
+        uint32_t pk[2][8];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 c2 = {c, c}, m2 = {-m_new, -m_new};
+        f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 sv = {sc[kb][r], sc[kb][r + 1]};
+                const f32x2 e = __builtin_elementwise_fma(sv, c2, m2);
+                f32x2 pv;
+                pv[0] = __builtin_amdgcn_exp2f(e[0]);
+                pv[1] = __builtin_amdgcn_exp2f(e[1]);
+                ps2 += pv;
+                pk[kb][r >> 1] = E::pack(pv[0], pv[1]);
+            }
+        l_run = l_run * alpha + (ps2[0] + ps2[1]);
+        // ---- O^T += V^T P^T ----
+        const char* sV = smem + bcur * BUF_B + TILE_B;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int lslot = 2 * s4 + hi;
+            uint4 pf;
+            pf.x = pk[s4 >> 1][4 * (s4 & 1) + 0]; pf.y = pk[s4 >> 1][4 * (s4 & 1) + 1];
+            pf.z = pk[s4 >> 1][4 * (s4 & 1) + 2]; pf.w = pk[s4 >> 1][4 * (s4 & 1) + 3];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + l31;
+                const uint4 vf = *(const uint4*)(sV + row * 128 + ((lslot ^ ((row >> 1) & 7)) << 4));
+                o_acc[db] = E::mfma(vf, pf, o_acc[db]);
+            }
+        }
+        bcur = bnxt;
+        svd_wait_dma();
+        __syncthreads();
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(t, s_a, s_b);
+        if (t + 1 < ntiles) tile(t + 1, s_b, s_a);
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q_valid) {
+        svd_bf16* Orow = O + ((int64_t)f * n_q + qrow) * ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 o;
+                o.x = E::pack(o_acc[db][4 * g + 0] * inv, o_acc[db][4 * g + 1] * inv);
+                o.y = E::pack(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv);
+                *(uint2*)(Orow + 32 * db + 8 * g + 4 * hi) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Per-pixel temporal attention (sequence <= 32 frames), head dim 64.  HBM-bound: q/k/v are read once, in place,
 // from the (frame, pixel, channel) token layout -- the reference's "(b t) s c -> (b s) t c" transposes never
 // happen.  One half-wave (32 lanes) per (batch, pixel, head): lane i holds query i in fp32 registers; K and V of
@@ -416,7 +580,11 @@ extern "C" int svd_attn_cross_d64(const svd_bf16* Q, int64_t ldq, const svd_bf16
     const int qblocks = (n_q + nw * 32 - 1) / (nw * 32);
     const int64_t nwg = (int64_t)frames * heads * qblocks;
     if (nwg > 0x7fffffff) return SVD_EINVAL;
-    if (wide && tpb == 2) {
+    static const bool pipe = [] { const char* e = getenv("SVD_ATTN_PIPE"); return e && e[0] == '1'; }();
+    if (wide && pipe) {
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_spatial_pipe_kernel<E>), dim3((unsigned)nwg), dim3(8 * 64), 3 * 2 * 8192,
+                                                     (hipStream_t)stream, Q, ldq, K, ldk, Vt, tok_ld, O, ldo, frames, n_q, n_k, frames_per_kv, heads, qblocks));
+    } else if (wide && tpb == 2) {
         static bool attr_set[2] = {false, false};
         SVD_DISPATCH_DTYPE(dtype, {
             if (!attr_set[E::kId == SVD_DTYPE_F16]) {
