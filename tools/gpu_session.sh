@@ -21,6 +21,8 @@ for step in "$@"; do
     paritysweep) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --plans sweep --timing > $O/fullsize_parity_sweep.txt 2>$O/parity_sweep.err; cat $O/fullsize_parity_sweep.txt; tail -3 $O/parity_sweep.err ;;
     attnpipe) for v in 0 1; do echo "SVD_ATTN_PIPE=$v"; SVD_ATTN_PIPE=$v timeout 200 python tools/attn_bench.py 2>/dev/null | tee $O/attn_bench_pipe$v.txt; done
               SVD_ATTN_PIPE=1 timeout 400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_kernels_product_sizes.py tests/test_gpu_i2v.py -m gpu -q -x -p no:cacheprovider -k "attn_spatial or attn_cross or attention" > $O/attn_pipe_tests.log 2>&1; tail -3 $O/attn_pipe_tests.log ;;
+    share2)   SVD_BENCH_SHARE_GPU=1 timeout 600 python bench.py --workload enhance --gpus 2 --denoise-steps 4 --steps 1 --warmup 0 --no-trace --no-cpu-baseline > $O/bench_enhance_2rank_shared_gpu.json 2>$O/share2_enh.err; cut -c1-700 $O/bench_enhance_2rank_shared_gpu.json; tail -2 $O/share2_enh.err
+              SVD_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --denoise-steps 2 --steps 6 --warmup 0 --no-trace --no-cpu-baseline > $O/bench_2rank_shared_gpu.json 2>$O/share2.err; cut -c1-300 $O/bench_2rank_shared_gpu.json; tail -2 $O/share2.err ;;
     norms)    timeout 200 python tools/norm_bench.py > $O/norm_bandwidth_after.txt 2>$O/norm_after.err
               grep -h "layernorm\|gn_stats" $O/norm_bandwidth_after.txt | head -12 ;;
     tune)     timeout 400 python tools/tune_gemm.py > $O/tune.log 2>$O/tune.err; cp streamingt2v_amd/gemm_tiles.json $O/gemm_tiles.json; head -8 $O/tune.log ;;
