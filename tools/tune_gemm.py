@@ -64,7 +64,7 @@ def main():
     import argparse
     import bench
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="'ar16': the 16-bit-stream AR forward + decode only (A/B runs of kernel variants)")
+    ap.add_argument("--only", default="", help="'ar16' / 'ar': the AR forward + decode only, under the all-16-bit plan / the default precision plan (A/B runs of kernel variants)")
     ap.add_argument("--out", default="", help="write the table here instead of streamingt2v_amd/gemm_tiles.json")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -74,7 +74,7 @@ def main():
     ops._tile_table = {}
     t0 = time.time()
     # both residual-stream forms of the UNet / ControlNet: their producers are different kernels (fp32 stream: `_o1` signatures)
-    plans = (("ar_chunk", True), ("c2", True), ("ar_chunk", False), ("c2", False)) if a.only != "ar16" else (("ar_chunk", False),)
+    plans = {"ar16": (("ar_chunk", False),), "ar": (("ar_chunk", True),)}.get(a.only, (("ar_chunk", True), ("c2", True), ("ar_chunk", False), ("c2", False)))
     for workload, stream in plans:
         ops.set_stream_f32(stream)                      # True: every block's stream in fp32 (= the round-4 default plan); False: the all-16-bit plan
         ops.set_precision_plan(exact_rim=True, cn_stream_f32=stream, stream_f32_min_ch=320 if stream else 0)
@@ -91,7 +91,7 @@ def main():
         torch.cuda.empty_cache()
     ops.set_stream_f32(False)
     ops.set_precision_plan(exact_rim=True, cn_stream_f32=True, stream_f32_min_ch=320)
-    if a.only != "ar16":
+    if not a.only:
         # enhancement stage: one I2VGen-XL UNet forward of a 38-frame window (CFG batch 2) at latent 90x160
         from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
         from streamingt2v_amd.params import init_by_name
