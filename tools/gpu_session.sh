@@ -23,6 +23,10 @@ for step in "$@"; do
               SVD_ATTN_PIPE=1 timeout 400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_kernels_product_sizes.py tests/test_gpu_i2v.py -m gpu -q -x -p no:cacheprovider -k "attn_spatial or attn_cross or attention" > $O/attn_pipe_tests.log 2>&1; tail -3 $O/attn_pipe_tests.log ;;
     share2)   SVD_BENCH_SHARE_GPU=1 timeout 600 python bench.py --workload enhance --gpus 2 --denoise-steps 4 --steps 1 --warmup 0 --no-trace --no-cpu-baseline > $O/bench_enhance_2rank_shared_gpu.json 2>$O/share2_enh.err; cut -c1-700 $O/bench_enhance_2rank_shared_gpu.json; tail -2 $O/share2_enh.err
               SVD_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --denoise-steps 2 --steps 6 --warmup 0 --no-trace --no-cpu-baseline > $O/bench_2rank_shared_gpu.json 2>$O/share2.err; cut -c1-300 $O/bench_2rank_shared_gpu.json; tail -2 $O/share2.err ;;
+    bench16)  timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --residual-stream 16 > $O/bench6_stream16_rim.json 2>/dev/null; cut -c50-75 $O/bench6_stream16_rim.json
+              timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --residual-stream 16 --no-exact-rim > $O/bench6_all16.json 2>/dev/null; cut -c50-75 $O/bench6_all16.json
+              timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_default.json 2>/dev/null; cut -c50-75 $O/bench6_default.json ;;
+    fullshare2) SVD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --workload full --gpus 2 --denoise-steps 2 --steps 1 --warmup 0 --no-trace --no-cpu-baseline > $O/bench_full_2rank_shared_gpu.json 2>$O/fullshare2.err; cut -c1-200 $O/bench_full_2rank_shared_gpu.json; grep -o '"parallelism": {[^}]*}' $O/bench_full_2rank_shared_gpu.json | cut -c1-600; tail -2 $O/fullshare2.err ;;
     norms)    timeout 200 python tools/norm_bench.py > $O/norm_bandwidth_after.txt 2>$O/norm_after.err
               grep -h "layernorm\|gn_stats" $O/norm_bandwidth_after.txt | head -12 ;;
     tune)     timeout 400 python tools/tune_gemm.py > $O/tune.log 2>$O/tune.err; cp streamingt2v_amd/gemm_tiles.json $O/gemm_tiles.json; head -8 $O/tune.log ;;
