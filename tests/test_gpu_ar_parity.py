@@ -170,9 +170,9 @@ def test_video_vs_reference_fp32_within_the_reference_autocast_envelope(world, s
     for got_e, t in zip(per_chunk, env["l2_max"]):
         assert got_e <= k * t, (per_chunk, env["l2_max"])
     if w["is16"]:
-        # the level statistic is a count of ~2 000 events among 221 k bytes (relative sampling sigma >= 2.4 %): "no worse than the reference's
-        # own autocast" is asserted with 10 % of slack for it (measured 0.84 % against the envelope's 0.82 % at 30 steps, 16-bit stream)
-        assert frac <= 1.1 * env["u8_frac_gt1"], (frac, env["u8_frac_gt1"])
+        # no slack (round 3 needed 1.1x here): under the default precision plan the HIP video has 0.49 % of its bytes off by > 1 level against the
+        # 0.82 % of the reference's own autocast execution at 30 steps
+        assert frac <= env["u8_frac_gt1"], (frac, env["u8_frac_gt1"])
 
 
 GOLD_SEEDS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ar_autocast_envelope_seeds.pt")

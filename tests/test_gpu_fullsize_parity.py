@@ -105,7 +105,8 @@ def test_shipped_architecture_small_latent_vs_reference(dtype, golden_dir):
         print(f"[shipped architecture, small latent, {dtype}] per-frame L2 abs max: StreamingWrapper {e_w:.3e} | VideoUNet (no control) {e_u:.3e} | "
               f"I2VGenXLUNet {e_i2v:.3e} | VideoDecoder {e_dec:.3e} | Encoder {e_enc:.3e}")
         k = 1.0 if f16 else 9.0          # bf16: one rounding is 8x coarser
-        assert e_w <= 1.5e-3 * k and e_u <= 1.25e-3 * k and e_i2v <= 1.8e-3 * k and e_dec <= 1.3e-3 * k and e_enc <= 1.2e-3 * k
+        # StreamingWrapper (A5) and VideoUNet without control (A7) under the default precision plan: north_star's 1e-3 (measured 0.76e-3 / 0.69e-3)
+        assert e_w <= 1e-3 * k and e_u <= 1e-3 * k and e_i2v <= 1.8e-3 * k and e_dec <= 1.3e-3 * k and e_enc <= 1.2e-3 * k
     finally:
         ops.set_element_dtype(None)
         torch.cuda.empty_cache()

@@ -8,7 +8,7 @@ Tolerance statement.  north_star asks for per-frame L2 <= 1e-3 against the fp32 
     per-frame RMS error / per-frame RMS of the reference <= 2e-2 (sampler 3e-2, chunk 5e-2), correlation >= 0.9995.
   * fp16 (what the reference's own "16-mixed" autocast computes in, config.yaml:8; same MFMA rate): 8x finer.
     asserted: relative <= 4e-3 (sampler 6e-3, chunk 1e-2) AND absolute per-frame L2 of StreamingWrapper.forward vs the
-    reference's output <= 1.25e-3 (measured 0.95e-3 mean, 1.04e-3 max).
+    reference's output <= 1e-3 (round 4, default precision plan: measured 0.65e-3 mean, 0.70e-3 max; rounds 2 / 3: 0.95e-3 / 1.04e-3).
 The measured values are printed (and tabulated in DESIGN.md) so that the gap to 1e-3 is visible, not hidden.
 """
 import os
@@ -138,9 +138,9 @@ def test_streaming_wrapper_vs_reference_golden(tiny, golden_dir):
                                image_only_indicator=torch.zeros(2, tu["T"], device="cuda"), ctrl_frames=inp["ctrl_frames"])
     e_abs, _ = report("StreamingWrapper.forward vs reference", out, gold["out"])
     if ELEM == torch.float16:
-        # north_star: per-frame L2 <= 1e-3 vs the reference.  Measured 0.95e-3 mean / 1.04e-3 max in fp16 (the reference's
-        # own autocast precision); asserted with 20 % head-room for run-to-run accumulation-order differences.
-        assert e_abs <= 1.25e-3, e_abs
+        # north_star: per-frame L2 <= 1e-3 vs the reference, asserted literally.  Measured 0.65e-3 mean / 0.70e-3 max in fp16 under the default
+        # precision plan of round 4 (1.04e-3 max with the all-16-bit arithmetic of rounds 2 / 3).
+        assert e_abs <= 1e-3, e_abs
     # no-ControlNet path (config C2): VideoUNet.forward with hs_control_* = None
     x = torch.cat((inp["x"], inp["concat"]), 1)
     out = tiny["unet"].forward(x, inp["t"], context=inp["crossattn"], y=inp["vector"], num_video_frames=tu["T"],
