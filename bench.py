@@ -664,7 +664,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 6 = one whole video for stage1, 1 otherwise)")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 6 = one whole video for stage1, so that both chunk types are warmed; 1 otherwise)")
     ap.add_argument("--workload", default="stage1", choices=["stage1", "c2", "ar_chunk", "c3", "enhance", "vfi", "full"])
     ap.add_argument("--parallelism", default="auto", choices=["auto", "pairs", "job", "replica", "cfg"],
                     help="auto (default) = pairs on an even number of GPUs, replica otherwise.  pairs: N/2 independent videos, each on a CFG pair of GPUs "
@@ -691,6 +691,8 @@ def main():
         args.parallelism = "pairs" if (args.gpus > 1 and args.gpus % 2 == 0) else "replica"
     if args.steps is None:
         args.steps = 6 if args.workload == "stage1" else 1
+    if args.warmup is None:
+        args.warmup = 6 if args.workload == "stage1" else 1
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
