@@ -692,7 +692,7 @@ def main():
     if args.steps is None:
         args.steps = 6 if args.workload == "stage1" else 1
     if args.warmup is None:
-        args.warmup = 6 if args.workload == "stage1" else 1
+        args.warmup = {"stage1": 6, "full": 0}.get(args.workload, 1)          # full: one job is 100 s; its stage 1 warms the kernels
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
