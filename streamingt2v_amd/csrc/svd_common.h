@@ -33,6 +33,33 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return fmaf(-fabsf(x), q, fmaxf(x, 0.0f));
 }
 
+// The same function on a PAIR (round 4; the GEGLU epilogue of the ff1 GEMMs evaluates 64 of them per lane and output tile and is bound by this VALU
+// work -- SQ counters: VALU pipes active 37 % of the kernel at K = 320 against 33 % MFMA-busy).  Same arithmetic, bit for bit; different instructions:
+// the degree-6 polynomial runs on v_pk_fma_f32 (two elements per issue slot) instead of six v_fmaak_f32 per element, and min(|x|, 7) / max(x, 0) are
+// single instructions (inline asm: the compiler brackets fminf / fmaxf with a canonicalising v_max x, x in IEEE mode -- three more VALU per element).
+// Round-3 ISA: ~17 issue slots per element; this form: ~10.5.
+typedef float svd_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ svd_f32x2 gelu_erf_f2(svd_f32x2 x) {
+    svd_f32x2 t, mx, ax;
+    asm("v_min_f32 %0, %2, |%1|" : "=v"(t[0]) : "v"(x[0]), "s"(7.0f));   // min(|x|, 7); the VOP3 form (|.| modifier) takes no literal: 7.0 in an SGPR
+    asm("v_min_f32 %0, %2, |%1|" : "=v"(t[1]) : "v"(x[1]), "s"(7.0f));
+    asm("v_max_f32 %0, 0, %1" : "=v"(mx[0]) : "v"(x[0]));                 // max(x, 0)
+    asm("v_max_f32 %0, 0, %1" : "=v"(mx[1]) : "v"(x[1]));
+    ax[0] = __builtin_fabsf(x[0]); ax[1] = __builtin_fabsf(x[1]);
+    const svd_f32x2 c6 = {1.775515804e-05f, 1.775515804e-05f}, c5 = {-6.477575890e-04f, -6.477575890e-04f}, c4 = {7.724042874e-03f, 7.724042874e-03f},
+                    c3 = {-5.292673725e-02f, -5.292673725e-02f}, c2 = {-4.590827371e-01f, -4.590827371e-01f}, c1 = {-1.151116856e+00f, -1.151116856e+00f},
+                    m1 = {-1.0f, -1.0f};
+    svd_f32x2 r = __builtin_elementwise_fma(c6, t, c5);
+    r = __builtin_elementwise_fma(r, t, c4);
+    r = __builtin_elementwise_fma(r, t, c3);
+    r = __builtin_elementwise_fma(r, t, c2);
+    r = __builtin_elementwise_fma(r, t, c1);
+    const svd_f32x2 e = __builtin_elementwise_fma(r, t, m1);
+    svd_f32x2 q;
+    q[0] = __builtin_amdgcn_exp2f(e[0]); q[1] = __builtin_amdgcn_exp2f(e[1]);
+    return __builtin_elementwise_fma(-ax, q, mx);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

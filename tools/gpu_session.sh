@@ -31,6 +31,10 @@ for step in "$@"; do
               grep -h "layernorm\|gn_stats" $O/norm_bandwidth_after.txt | head -12 ;;
     tune)     timeout 400 python tools/tune_gemm.py > $O/tune.log 2>$O/tune.err; cp streamingt2v_amd/gemm_tiles.json $O/gemm_tiles.json; head -8 $O/tune.log ;;
     spbisect) timeout 400 python tools/sp_delta_bisect.py > $O/sp_delta_bisect.txt 2>$O/spbisect.err; tail -4 $O/sp_delta_bisect.txt; tail -3 $O/spbisect.err ;;
+    geluab2)  for L in libsvdhip_pv_scalargelu.so libsvdhip.so libsvdhip_pv_scalargelu.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>&1 | tee -a $O/geglu_ab.txt; done ;;
+    geluab)   timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "geglu or many_tiles" > $O/geglu_tests.log 2>&1; tail -2 $O/geglu_tests.log
+              for L in libsvdhip_pv_scalargelu.so libsvdhip.so libsvdhip_pv_scalargelu.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>/dev/null | tee -a $O/geglu_ab.txt; done
+              for L in libsvdhip_pv_scalargelu.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_$L.json 2>/dev/null; echo $L; cut -c50-75 $O/bench6_$L.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_$L.json; done ;;
     bench6)   timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6.json 2>$O/bench6.err; cut -c1-420 $O/bench6.json ;;
     bench6ab) SVD_EXACT_RIM=0 SVD_CN_STREAM_F32=0 SVD_STREAM_F32_MIN_CH=0 timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_plan_off.json 2>$O/bench6_off.err
               timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_plan_default.json 2>$O/bench6_def.err
