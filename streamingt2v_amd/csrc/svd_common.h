@@ -37,7 +37,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 // work -- SQ counters: VALU pipes active 37 % of the kernel at K = 320 against 33 % MFMA-busy).  Same arithmetic, bit for bit; different instructions:
 // the degree-6 polynomial runs on v_pk_fma_f32 (two elements per issue slot) instead of six v_fmaak_f32 per element, and min(|x|, 7) / max(x, 0) are
 // single instructions (inline asm: the compiler brackets fminf / fmaxf with a canonicalising v_max x, x in IEEE mode -- three more VALU per element).
-// Round-3 ISA: ~17 issue slots per element; this form: ~10.5.
+// Round-3 ISA: ~17 instructions per element; this form: ~10.5 (a v_pk_fma_f32 costs what two v_fma_f32 cost: the gain is the five plain ones).
 typedef float svd_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ svd_f32x2 gelu_erf_f2(svd_f32x2 x) {
     svd_f32x2 t, mx, ax;

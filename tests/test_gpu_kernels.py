@@ -117,6 +117,31 @@ def test_gemm_geglu(ops, cfg):
     check(f"gemm geglu cfg{cfg}", out, v * F.gelu(g), 3e-2, 1e-2)
 
 
+def test_geglu_gate_function_against_exact_erf(ops):
+    """The GEGLU epilogue's gate function alone, on every 16-bit gate value in [-9.5, 9.5]: value = 1 (bias only), gate = x through a unit
+    weight, so the output is rn16(gelu(x)) -- the exact-erf GELU of the reference's GEGLU (attention.py:99-101) as csrc/svd_common.h
+    gelu_erf_f2 evaluates it (x Phi(x) through q = 2^(r(|x|) |x| - 1), one v_exp_f32), to well inside one output rounding, tails and
+    16-bit subnormals included.  (Round 4 also ran this test on an LDS-table form of Phi, |Phi error| <= 2e-6: the 4e-6 |x| slack is that form's.)"""
+    from streamingt2v_amd.video_model import pack_geglu
+    M, K, n_out = 40960, 64, 64
+    x = torch.linspace(-9.5, 9.5, M).to(BF16)
+    a = torch.zeros(M, K, dtype=BF16); a[:, 0] = x
+    w = torch.zeros(2 * n_out, K); w[n_out:, 0] = 1.0
+    b = torch.zeros(2 * n_out); b[:n_out] = 1.0
+    wp, bp = pack_geglu(w, b)
+    exact = (x.double() * 0.5 * torch.erfc(-x.double() / math.sqrt(2.0)))
+    for cfg in (0, 2, 8, 20):
+        out = ops.gemm(a.cuda(), wp.to(BF16).cuda(), bias=bp.cuda(), geglu=True, tile_cfg=cfg).double().cpu()
+        assert out.shape == (M, n_out) and torch.equal(out[:, :1].expand(-1, n_out), out)
+        err = (out[:, 0] - exact).abs()
+        mant, emin = (7, -126) if BF16 == torch.bfloat16 else (10, -14)   # bound: half a spacing of the output type at the exact value + the table's 4e-6 |x|
+        spacing = torch.exp2(torch.floor(torch.log2(exact.abs().clamp(min=1e-300))).clamp(min=emin) - mant)
+        bound = 0.5 * spacing + 4e-6 * x.double().abs().clamp(min=1.0)
+        worst = (err - bound).max().item()
+        print(f"[geglu gate function cfg{cfg}] max abs err {err.max().item():.3e}, worst margin over (one output rounding + 4e-6 |x|) {worst:.3e}")
+        assert worst <= 0, (cfg, worst)
+
+
 @pytest.mark.parametrize("stride,ups,cin,cout,H,W", [(1, 0, 64, 128, 9, 16), (2, 0, 64, 64, 18, 32), (1, 1, 128, 64, 9, 16),
                                                      (1, 0, 32, 96, 12, 20), (1, 0, 320, 320, 16, 16)])
 def test_gemm_conv3x3(ops, stride, ups, cin, cout, H, W):
