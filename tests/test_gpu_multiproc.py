@@ -74,7 +74,8 @@ def _worker(rank, world, port, out):
         # (1) sequence parallelism alone, degree 2, CFG batch 2 (B = 2: the batch interleave of the all-to-alls); world 4: groups {0,1} {2,3}
         sp_groups = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
         wrap.sp = parallel.SeqParallel(sp_groups[rank // 2])
-        res["e_sp"] = _rel(wrap.forward(win["x"], win["t"], c, **kw), ref)
+        y_sp = wrap.forward(win["x"], win["t"], c, **kw)
+        res["e_sp"] = _rel(y_sp, ref)
         kw0 = dict(kw, ctrl_frames=None)                                            # chunk 0: no ControlNet / CAM
         ref0 = StreamingWrapper(unet, cn, TC).forward(win["x"], win["t"], c, **kw0)
         res["e_sp0"] = _rel(wrap.forward(win["x"], win["t"], c, **kw0), ref0)
@@ -108,6 +109,16 @@ def _worker(rank, world, port, out):
         res["pairs_decode_identical"] = bool(torch.equal(StreamingSVD(wrap, pvae).decode_first_stage(zdec, clamp=True), one))
         res["pairs_videos"] = (pplan.n_videos, pplan.video_id)
         torch.cuda.synchronize()
+        if rank == 0:
+            # against the fp32 CPU ORACLE (round-3 review): the sharded forward must be as close to it as the single-process forward is -- the SP delta is
+            # rounding flips downstream of the pooled GroupNorm statistics (tools/sp_delta_bisect.py), not a different computation
+            from oracle import svd_oracle as O
+            ocfg = O.Cfg(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"], channel_mult=tu["channel_mult"],
+                         cond_embed_channels=tu["cond_embed"])
+            cpu = {k: v.cpu() for k, v in win.items()}
+            yo = O.streaming_wrapper(init_by_name(unet.spec(), seed=1), init_by_name(cn.spec(), seed=2), ocfg, cpu["x"], cpu["t"],
+                                     {k: cpu[k] for k in ("concat", "crossattn", "vector")}, 2, T, TC, cpu["ctrl_frames"]).cuda()
+            res["single_vs_oracle"], res["sp_vs_oracle"] = _rel(ref, yo), _rel(y_sp, yo)
         out.put(res)
     finally:
         dist.destroy_process_group()
@@ -131,6 +142,9 @@ def test_job_plan_on_hip_kernels_multi_process(world):
         # the sharded forward differs from the single-process one only in the summation order of the pooled GroupNorm statistics
         # (per-rank fp32 partials + fp64 all-reduce): a few 16-bit roundings flip downstream
         assert d["e_sp"] < 2e-3 and d["e_sp0"] < 2e-3, d
+        if d["rank"] == 0:
+            print(f"[multi-process HIP path, world {world}] relative L2 vs the fp32 CPU oracle: single process {d['single_vs_oracle']:.3e}, sequence parallel {d['sp_vs_oracle']:.3e}")
+            assert d["sp_vs_oracle"] <= 1.05 * d["single_vs_oracle"], d
         assert d["e_job"] < 4e-3, d
         assert d["decode_identical"] and d["scaling"] == "strong"
         assert d["pairs_bit_identical"] and d["pairs_decode_identical"] and d["pairs_videos"] == (world // 2, d["rank"] // 2), d
