@@ -10,6 +10,7 @@
 #   enhance     bench.py --workload enhance + its rocprofv3 roofline table  full        bench.py --workload full
 #   pmc         PMC counter passes of the dominant GEMM signatures and the spatial attention (tools/pmc_round4.sh)
 #   phase       tools/gemm_phase_profile.py on a probe build (make -C streamingt2v_amd/csrc gvariant NAME=phase PROBE_DEFS=-DSVD_GEMM_PHASE_PROFILE PV_CFGS='...'); PHASE_CFGS / PHASE_SHAPES select
+#   tailab / tailbench   kernel tests + tools/geglu_ab.py (/ bench6) of libsvdhip.so against a variant library libsvdhip_pv_tail0.so (any GEMM-source A/B: build the variant's GEMM objects with the switch, link with the main objects)
 #   geluab(2)   A/B of the GEGLU epilogue against a variant library built with -DSVD_GEGLU_SCALAR_GELU (libsvdhip_pv_scalargelu.so): tests + tools/geglu_ab.py + bench6 (2: geglu_ab only)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
 for step in "$@"; do
@@ -34,6 +35,10 @@ for step in "$@"; do
     tune)     timeout 400 python tools/tune_gemm.py > $O/tune.log 2>$O/tune.err; cp streamingt2v_amd/gemm_tiles.json $O/gemm_tiles.json; head -8 $O/tune.log ;;
     spbisect) timeout 400 python tools/sp_delta_bisect.py > $O/sp_delta_bisect.txt 2>$O/spbisect.err; tail -4 $O/sp_delta_bisect.txt; tail -3 $O/spbisect.err ;;
     phase)    SVD_LIB_FILE=libsvdhip_pv_phase.so timeout 300 python tools/gemm_phase_profile.py ${PHASE_CFGS:-20,8,17,21,22,18} ${PHASE_SHAPES:-} 2>&1 | grep -v amdgpu.ids | tee $O/gemm_phase_profile.txt ;;
+    tailab)   timeout 400 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "gemm_plain or many_tiles or geglu or implicit_views or conv3x3 or temporal or x3" > $O/tail_tests.log 2>&1; tail -2 $O/tail_tests.log
+              if grep -q failed $O/tail_tests.log; then echo "kernel tests FAILED: skipping the A/B"; else
+              for L in libsvdhip_pv_tail0.so libsvdhip.so libsvdhip_pv_tail0.so libsvdhip.so; do echo "# lib $L" | tee -a $O/tail_ab.txt; SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>&1 | grep "M=" | tee -a $O/tail_ab.txt; done; fi ;;
+    tailbench) for L in libsvdhip_pv_tail0.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_$L.json 2>/dev/null; echo $L; cut -c50-75 $O/bench6_$L.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_$L.json; done ;;
     geluab2)  for L in libsvdhip_pv_scalargelu.so libsvdhip.so libsvdhip_pv_scalargelu.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>&1 | tee -a $O/geglu_ab.txt; done ;;
     geluab)   timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "geglu or many_tiles" > $O/geglu_tests.log 2>&1; tail -2 $O/geglu_tests.log
               for L in libsvdhip_pv_scalargelu.so libsvdhip.so libsvdhip_pv_scalargelu.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>/dev/null | tee -a $O/geglu_ab.txt; done
