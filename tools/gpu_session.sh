@@ -35,6 +35,7 @@ for step in "$@"; do
     tune)     timeout 400 python tools/tune_gemm.py > $O/tune.log 2>$O/tune.err; cp streamingt2v_amd/gemm_tiles.json $O/gemm_tiles.json; head -8 $O/tune.log ;;
     spbisect) timeout 400 python tools/sp_delta_bisect.py > $O/sp_delta_bisect.txt 2>$O/spbisect.err; tail -4 $O/sp_delta_bisect.txt; tail -3 $O/spbisect.err ;;
     phase)    SVD_LIB_FILE=libsvdhip_pv_phase.so timeout 300 python tools/gemm_phase_profile.py ${PHASE_CFGS:-20,8,17,21,22,18} ${PHASE_SHAPES:-} 2>&1 | grep -v amdgpu.ids | tee $O/gemm_phase_profile.txt ;;
+    cfgab)    SVD_LIB_FILE=${CFGAB_LIB:-libsvdhip_pv_xpf.so} timeout 250 python tools/gemm_cfg_ab.py ${CFGAB_CFGS:-20,8,21,17,26,18,25,19,27} 20 2>&1 | grep -v amdgpu.ids | tee $O/gemm_cfg_ab.txt ;;
     tailab)   timeout 400 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "gemm_plain or many_tiles or geglu or implicit_views or conv3x3 or temporal or x3" > $O/tail_tests.log 2>&1; tail -2 $O/tail_tests.log
               if grep -q failed $O/tail_tests.log; then echo "kernel tests FAILED: skipping the A/B"; else
               for L in libsvdhip_pv_tail0.so libsvdhip.so libsvdhip_pv_tail0.so libsvdhip.so; do echo "# lib $L" | tee -a $O/tail_ab.txt; SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>&1 | grep "M=" | tee -a $O/tail_ab.txt; done; fi ;;
