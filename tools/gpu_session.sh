@@ -10,6 +10,7 @@
 #   enhance     bench.py --workload enhance + its rocprofv3 roofline table  full        bench.py --workload full
 #   pmc         PMC counter passes of the dominant GEMM signatures and the spatial attention (tools/pmc_round4.sh)
 #   phase       tools/gemm_phase_profile.py on a probe build (make -C streamingt2v_amd/csrc gvariant NAME=phase PROBE_DEFS=-DSVD_GEMM_PHASE_PROFILE PV_CFGS='...'); PHASE_CFGS / PHASE_SHAPES select
+#   cfgab       tools/gemm_cfg_ab.py on a probe library with experimental tiles (CFGAB_LIB, CFGAB_CFGS): per-tile timings + bit checksums on the job's GEMM shapes
 #   tailab / tailbench   kernel tests + tools/geglu_ab.py (/ bench6) of libsvdhip.so against a variant library libsvdhip_pv_tail0.so (any GEMM-source A/B: build the variant's GEMM objects with the switch, link with the main objects)
 #   geluab(2)   A/B of the GEGLU epilogue against a variant library built with -DSVD_GEGLU_SCALAR_GELU (libsvdhip_pv_scalargelu.so): tests + tools/geglu_ab.py + bench6 (2: geglu_ab only)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
