@@ -272,7 +272,8 @@ int svd_adaptive_avgpool_tokens(const svd_bf16* X, int64_t ldx, svd_bf16* Y, int
                                 int32_t win, int32_t hout, int32_t wout, int32_t channels, int32_t dtype, svd_stream_t stream);
 /* I2VGenXLTransformerTemporalEncoder on the 4-channel image latents (unet_i2vgen_xl.py:110-160, call site :700-709):
  * X rows (b, f, p) with >= 4 channels; params = ln_w[4] ln_b[4] wq[8][4] wk[8][4] wv[8][4] wo[4][8] bo[4] w1[16][4] b1[16]
- * w2[4][16] b2[4] (288 floats); Y fp32 NCHW [(b f), 4, pix].  frames <= 128. */
+ * w2[4][16] b2[4] (288 floats); Y fp32 NCHW [(b f), 4, pix].  frames <= 128.  X: 16-bit rows, or fp32 rows (ldx in floats, 16-byte aligned)
+ * with dtype | SVD_DTYPE_IN_F32 (round 5: the enhancer's precision plan keeps the image-latent projection fp32 up to this kernel). */
 int svd_i2v_image_temporal_encoder(const svd_bf16* X, int64_t ldx, const float* params, float* Y, int32_t batch,
                                    int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream);
 /* Classifier-free guidance + one DDIM step (eta 0) on fp32 latents (pipeline_i2vgen_xl.py:872-885 + diffusers

@@ -289,6 +289,60 @@ def fullsize_inputs():
                 ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
 
 
+# Round 5: the same forward at the two ends of the AYS-30 schedule, on fresh draws of every input (the round-4 golden sits at sigma = 7.47).
+# c_noise, the timestep embedding and the activation statistics all move with sigma; x is what the Denoiser hands the network at that
+# sigma: (latent + sigma * noise) * c_in with c_in = 1 / sqrt(sigma^2 + 1)  (denoiser_scaling.py:51-59).
+FULLSIZE_SIGMA_CASES = {"s700": dict(sigma=700.0, seed=7575), "s0p063": dict(sigma=6.30212713e-02, seed=7676)}
+
+
+def fullsize_inputs_sigma(name):
+    import math
+    cs = FULLSIZE_SIGMA_CASES[name]
+    g = _gen(cs["seed"])
+    c = FULLSIZE_CASE
+    T, h, w = c["T"], c["h"], c["w"]
+    F = 2 * T
+    sigma = cs["sigma"]
+    lat = torch.randn(T, 4, h, w, generator=g).mul(0.8)
+    x = (lat + sigma * torch.randn(T, 4, h, w, generator=g)) / math.sqrt(sigma * sigma + 1.0)
+    concat = torch.randn(1, 4, h, w, generator=g).mul(0.8).repeat(T, 1, 1, 1)
+    return dict(x=torch.cat((x, x)), t=torch.full((F,), 0.25 * math.log(sigma)),
+                concat=torch.cat((torch.zeros(T, 4, h, w), concat)),
+                crossattn=torch.cat((torch.zeros(T, 1, 1024), torch.randn(1, 1, 1024, generator=g).repeat(T, 1, 1))),
+                vector=(torch.randn(1, 768, generator=g) * 0.5).repeat(F, 1),
+                ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
+
+
+# Round 5: one chunk's denoise + decode at the shipped size through the reference's own sampler / denoiser / guider / wrapper / decoder:
+# 2 Euler steps of the AYS schedule (sigma 700 -> 0.002 -> 0: both ends of the schedule on one trajectory), guidance 1.5 -> 3.0, then
+# decode_first_stage of the first group of 8 frames (oracle/make_golden_fullsize.py --which chunk).
+FULLSIZE_CHUNK_CASE = dict(steps=2, decode_frames=8, seed=7777)
+
+
+def fullsize_chunk_inputs():
+    g = _gen(FULLSIZE_CHUNK_CASE["seed"])
+    c = FULLSIZE_CASE
+    T, h, w = c["T"], c["h"], c["w"]
+    cond = dict(concat=torch.randn(1, 4, h, w, generator=g).mul(0.8).repeat(T, 1, 1, 1), crossattn=torch.randn(1, 1, 1024, generator=g).repeat(T, 1, 1),
+                vector=(torch.randn(1, 768, generator=g) * 0.5).repeat(T, 1))
+    uc = dict(concat=torch.zeros(T, 4, h, w), crossattn=torch.zeros(T, 1, 1024), vector=cond["vector"].clone())
+    return dict(noise=torch.randn(T, 4, h, w, generator=g), c=cond, uc=uc, ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
+
+
+# Round 5: the enhancer UNet at its shipped configuration AND latent size (90 x 160 = 720 x 1280 pixels; N = 14 400 spatial attention),
+# CFG 2 x 4 frames (oracle/make_golden_i2v_fullarch.py --fullres)
+I2V_FULLRES_CASE = dict(F=4, h=90, w=160, text_tokens=77, seed=6)
+
+
+def i2v_fullres_inputs():
+    g = _gen(779)
+    c = I2V_FULLRES_CASE
+    B, Fr, h, w, cd = 2, c["F"], c["h"], c["w"], 1024
+    return dict(sample=torch.randn(B, 4, Fr, h, w, generator=g), t=torch.tensor(481), fps=torch.tensor([38, 38]),
+                image_latents=torch.randn(B, 4, Fr, h, w, generator=g) * 0.7, image_embeddings=torch.randn(B, cd, generator=g),
+                text=torch.randn(B, c["text_tokens"], cd, generator=g))
+
+
 def fullsize_vae_inputs():
     g = _gen(7373)
     return dict(z=torch.randn(2, 4, 72, 128, generator=g))

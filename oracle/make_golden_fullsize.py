@@ -1,6 +1,6 @@
 """FULL-SIZE goldens from the reference's UNMODIFIED modules (build container only; ~30 GB of RAM, ~10 minutes on 8 cores):
 
-    python oracle/make_golden_fullsize.py [--which wrapper|vae|both]
+    python oracle/make_golden_fullsize.py [--which wrapper|vae|both|sigmas|chunk|round5]
 
   * StreamingWrapper.forward (code/models/diffusion/wrappers.py:23-78) at the shipped architecture AND the shipped problem size:
     CFG batch 2 x 25 frames, latent 72x128 (576x1024 pixels), ControlNet on 2 x 7 frames of 576x1024 control pixels
@@ -9,6 +9,9 @@
     pixels, fp32 like the reference's decode (config.yaml:310).  The output (14 MB) is stored on a seeded random 1/16 subset of the
     pixel positions of every frame (cases.fullsize_pixel_subset): 36 864 positions per frame and channel
                                                                                   -> tests/golden/vae_fullsize.pt (0.9 MB)
+  * round 5 (--which sigmas): the same forward at sigma = 700 and sigma = 0.063 on fresh draws -> wrapper_fullsize_s700.pt, _s0p063.pt
+  * round 5 (--which chunk): 2 Euler steps of the reference's sampler / denoiser / guider around the wrapper + fp32 decode of 8 frames
+                                                                                  -> tests/golden/chunk_fullsize.pt
 The timing lines this script prints are the reference's own CPU numbers (core count stated): profiles/r02_cpu_reference_forward.txt.
 Inputs are re-derived from seeds (oracle/cases.py); weights by name (streamingt2v_amd.params.init_by_name), seeds as in FULLARCH_CASE.
 """
@@ -24,7 +27,8 @@ sys.path.insert(0, ROOT)
 from oracle import ref_bootstrap  # noqa: E402
 
 ref_bootstrap.install()
-from oracle.cases import FULLSIZE_CASE, full_unet_kwargs, fullsize_inputs, fullsize_pixel_subset, fullsize_vae_inputs  # noqa: E402
+from oracle.cases import (FULLSIZE_CASE, FULLSIZE_CHUNK_CASE, FULLSIZE_SIGMA_CASES, full_unet_kwargs, fullsize_chunk_inputs, fullsize_inputs,  # noqa: E402
+                          fullsize_inputs_sigma, fullsize_pixel_subset, fullsize_vae_inputs)
 from streamingt2v_amd.params import Spec, init_by_name  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -39,7 +43,13 @@ def load_by_name(module, seed):
     return sd
 
 
-def wrapper():
+_BUILT = {}
+
+
+def build_wrapper():
+    """the reference's VideoUNet + ControlNet.from_unet + StreamingWrapper at the shipped architecture, weights by name (built once per process)"""
+    if "wrap" in _BUILT:
+        return _BUILT["wrap"]
     from models.control.controlnet import ControlNet
     from models.diffusion.video_model import VideoUNet
     from models.diffusion.wrappers import StreamingWrapper
@@ -53,19 +63,89 @@ def wrapper():
                               condition_encoder="", conditioning_embedding_out_channels=[32, 96, 256, 512]).eval()
     load_by_name(cn, seed=c["seed_cn"])
     print(f"reference modules built and loaded in {time.time() - t0:.0f} s", flush=True)
-    inp = fullsize_inputs()
-    T, Tc = c["T"], c["Tc"]
-    wrap = StreamingWrapper(diffusion_model=unet, controlnet=cn, num_frame_conditioning=Tc)
+    _BUILT["wrap"] = StreamingWrapper(diffusion_model=unet, controlnet=cn, num_frame_conditioning=c["Tc"])
+    return _BUILT["wrap"]
+
+
+def build_decoder():
+    if "dec" in _BUILT:
+        return _BUILT["dec"]
+    from models.svd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    kw = dict(ch=128, out_ch=3, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=256,
+              z_channels=4, double_z=True, attn_type="vanilla")
+    dec = VideoDecoder(video_kernel_size=[3, 1, 1], **kw).eval()
+    load_by_name(dec, seed=35)
+    _BUILT["dec"] = dec
+    return dec
+
+
+def _forward(inp, tag):
+    c = FULLSIZE_CASE
+    T = c["T"]
+    wrap = build_wrapper()
     kw = dict(batch_size=2, num_video_frames=T, image_only_indicator=torch.zeros(2, T), ctrl_frames=inp["ctrl_frames"])
     cond = {k: inp[k] for k in ("concat", "crossattn", "vector")}
     t0 = time.time()
     ref = wrap(inp["x"], inp["t"], dict(cond), **dict(kw))
     dt = time.time() - t0
-    print(f"[cpu reference] StreamingWrapper.forward, CFG 2 x {T} frames @ {c['h']}x{c['w']} latent, fp32, {torch.get_num_threads()} threads "
+    print(f"[cpu reference] StreamingWrapper.forward ({tag}), CFG 2 x {T} frames @ {c['h']}x{c['w']} latent, fp32, {torch.get_num_threads()} threads "
           f"on {os.cpu_count()} cores: {dt:.1f} s  (181.96 TFLOP algorithmic => {181.96 / dt:.3f} TFLOP/s); |out| std {ref.std():.4f}", flush=True)
     assert torch.isfinite(ref).all()
+    return ref, dt
+
+
+def wrapper():
+    ref, dt = _forward(fullsize_inputs(), "sigma 7.47")
     path = os.path.join(OUT, "wrapper_fullsize.pt")
     torch.save({"out": ref.clone(), "cpu_seconds": dt, "threads": torch.get_num_threads()}, path)
+    print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+
+
+def sigmas():
+    """round 5: the same forward at both ends of the AYS schedule on fresh draws -> tests/golden/wrapper_fullsize_<name>.pt"""
+    for name, cs in FULLSIZE_SIGMA_CASES.items():
+        ref, dt = _forward(fullsize_inputs_sigma(name), f"sigma {cs['sigma']:g}")
+        path = os.path.join(OUT, f"wrapper_fullsize_{name}.pt")
+        torch.save({"out": ref.clone(), "sigma": cs["sigma"], "cpu_seconds": dt, "threads": torch.get_num_threads()}, path)
+        print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+
+
+def chunk():
+    """round 5: sampler o denoiser o guider o wrapper o decoder at the shipped size -- the arithmetic of `_generate_conditional_output`
+    (diffusion_trainer/streaming_svd.py:203-221) and `decode_first_stage` (:123-151) with the reference's own EulerEDMSampler
+    (AlignYourSteps, 2 steps: sigma 700 -> 0.002 -> 0), Denoiser + VScalingWithEDMcNoise, LinearPredictionGuider (1.5 -> 3.0), on seeded
+    conditioning; the first decode group (8 frames) is decoded in fp32 and clamped -> tests/golden/chunk_fullsize.pt"""
+    from models.svd.sgm.modules.diffusionmodules.denoiser import Denoiser
+    from models.svd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    c, cc = FULLSIZE_CASE, FULLSIZE_CHUNK_CASE
+    T = c["T"]
+    wrap = build_wrapper()
+    dec = build_decoder()
+    inp = fullsize_chunk_inputs()
+    den = Denoiser({"target": "models.svd.sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = EulerEDMSampler(s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, num_steps=cc["steps"], verbose=False, device="cpu",
+                              discretization_config={"target": "models.diffusion.discretizer.AlignYourSteps", "params": {"sigma_max": 700.0}},
+                              guider_config={"target": "models.svd.sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                                             "params": {"max_scale": 3.0, "min_scale": 1.5, "num_frames": T}})
+    add = dict(batch_size=2, num_video_frames=T, image_only_indicator=torch.zeros(2, T), ctrl_frames=inp["ctrl_frames"])
+    net_out = []
+
+    def net(x, t, cd, **kw):
+        o = wrap(x, t, cd, **kw)
+        net_out.append(o.clone())
+        return o
+    t0 = time.time()
+    z = sampler(lambda x, s, cd: den(net, x, s, cd, **dict(add)), inp["noise"].clone(), cond=inp["c"], uc=inp["uc"])
+    t1 = time.time()
+    n = cc["decode_frames"]
+    frames = dec(z[:n].float() / 0.18215, timesteps=n).clamp(-1.0, 1.0)          # decode_first_stage: one group of 8, fp32 (config.yaml:310); clamp :221
+    t2 = time.time()
+    print(f"[cpu reference] {cc['steps']} Euler steps (2 x {T} frames each) {t1 - t0:.0f} s + decode of {n} frames {t2 - t1:.0f} s; |z| std {z.std():.4f} "
+          f"|frames| std {frames.std():.4f}, clamped {100 * (frames.abs() == 1).float().mean():.2f} %", flush=True)
+    idx = fullsize_pixel_subset(frames.shape[-2] * frames.shape[-1])
+    path = os.path.join(OUT, "chunk_fullsize.pt")
+    torch.save({"z": z.clone(), "frames_subset": frames.flatten(2)[:, :, idx].clone(), "frame_rms": frames.flatten(1).pow(2).mean(1).sqrt(),
+                "net_out_step0": net_out[0].half(), "cpu_seconds": t2 - t0, "threads": torch.get_num_threads()}, path)
     print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
@@ -99,6 +179,10 @@ def main():
         vae()
     if a.which in ("both", "wrapper"):
         wrapper()
+    if a.which in ("sigmas", "round5"):
+        sigmas()
+    if a.which in ("chunk", "round5"):
+        chunk()
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const svd_bf16* _
 // One wave per (batch, pixel); a lane owns frames `lane` and `lane + 64` (F <= 128: the 38-frame windows use one slot, the
 // single 100-frame window of the no-blending mode two); keys/values travel by cross-lane reads.  Everything fp32.
 // params: ln_w[4] ln_b[4] wq[8][4] wk[8][4] wv[8][4] wo[4][8] bo[4] w1[16][4] b1[16] w2[4][16] b2[4]   (288 floats)
-template <class E>
+template <class E, bool IN32>
 __global__ __launch_bounds__(256) void i2v_image_encoder_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const float* __restrict__ prm,
                                                                 float* __restrict__ Y, int batch, int frames, int pix) {
     __shared__ float P[288];
@@ -56,8 +56,13 @@ __global__ __launch_bounds__(256) void i2v_image_encoder_kernel(const svd_bf16* 
             const int fr0 = lane + 64 * sl;
             const int fr = fr0 < frames ? fr0 : frames - 1;
             const int64_t row = ((int64_t)b * frames + fr) * pix + p;
-            const uint2 u = *(const uint2*)(X + row * ldx);
-            x[sl][0] = E::lo(u.x); x[sl][1] = E::hi(u.x); x[sl][2] = E::lo(u.y); x[sl][3] = E::hi(u.y);
+            if constexpr (IN32) {              // fp32 rows (the enhancer's precision plan: the image-latent projection stays fp32 up to here)
+                const float4 u = *(const float4*)((const float*)X + row * ldx);
+                x[sl][0] = u.x; x[sl][1] = u.y; x[sl][2] = u.z; x[sl][3] = u.w;
+            } else {
+                const uint2 u = *(const uint2*)(X + row * ldx);
+                x[sl][0] = E::lo(u.x); x[sl][1] = E::hi(u.x); x[sl][2] = E::lo(u.y); x[sl][3] = E::hi(u.y);
+            }
             // LayerNorm(4), eps 1e-5
             const float mean = 0.25f * ((x[sl][0] + x[sl][1]) + (x[sl][2] + x[sl][3]));
             float var = 0.f, n[4];
@@ -179,11 +184,17 @@ extern "C" int svd_adaptive_avgpool_tokens(const svd_bf16* X, int64_t ldx, svd_b
 extern "C" int svd_i2v_image_temporal_encoder(const svd_bf16* X, int64_t ldx, const float* params, float* Y, int32_t batch,
                                               int32_t frames, int32_t pix, int32_t dtype, svd_stream_t stream) {
     if (!X || !params || !Y || batch <= 0 || frames <= 0 || frames > 128 || pix <= 0) return SVD_EINVAL;
-    if (ldx % 4 || ((uintptr_t)X & 7)) return SVD_EINVAL;
+    const bool in32 = (dtype & SVD_DTYPE_IN_F32) != 0;
+    if (ldx % 4 || ((uintptr_t)X & (in32 ? 15 : 7))) return SVD_EINVAL;
     int64_t blocks = ((int64_t)batch * pix + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(i2v_image_encoder_kernel<E>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, ldx,
-                                                 params, Y, batch, frames, pix));
+    if (in32) {
+        SVD_DISPATCH_DTYPE(dtype & 0xff, hipLaunchKernelGGL((i2v_image_encoder_kernel<E, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                                            X, ldx, params, Y, batch, frames, pix));
+    } else {
+        SVD_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((i2v_image_encoder_kernel<E, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                                     X, ldx, params, Y, batch, frames, pix));
+    }
     SVD_CHECK_LAUNCH("i2v_image_temporal_encoder");
     return SVD_OK;
 }

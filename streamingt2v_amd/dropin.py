@@ -73,3 +73,30 @@ def install(model, device="cuda", unet_cfg=None, vae_cfg=None, state_dict=None, 
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
     return wrapper, dec
+
+
+def install_enhancer(pipeline, device="cuda", cfg=None, state_dict=None):
+    """pipeline: the reference's `I2VGenXLPipeline` (code/i2v_enhance/pipeline_i2vgen_xl.py) after `from_pretrained` / construction
+    (i2v_enhance_interface.py:65-83).  Builds the MI355X mirror of its UNet from the same weights (strict: the 1511 keys of the vendored
+    I2VGenXLUNet) and puts it in the UNet's place, so that the reference's unmodified `__call__` denoise loop (:841-913) calls
+    `self.unet(latent_model_input, t, encoder_hidden_states=, fps=, image_latents=, image_embeddings=, cross_attention_kwargs=,
+    return_dict=False, use_memopt=)[0]` (:857-867) on libsvdhip.so.  Returns the wrapped streamingt2v_amd.i2vgen_unet.I2VGenXLUNet.
+    Executed by tests/test_dropin_enhancer_reference.py (CPU statements of the launchers, unmodified reference pipeline)."""
+    from .i2vgen_unet import I2VConfig, I2VGenXLUNet
+    old = pipeline.unet
+    sd = state_dict if state_dict is not None else old.state_dict()
+    if cfg is None:
+        oc = getattr(old, "config", None)
+        get = (lambda k, d: (oc[k] if isinstance(oc, dict) else getattr(oc, k)) if (oc is not None and (k in oc if isinstance(oc, dict) else hasattr(oc, k))) else d)
+        boc = tuple(get("block_out_channels", (320, 640, 1280, 1280)))
+        down = tuple(get("down_block_types", ("CrossAttnDownBlock3D",) * (len(boc) - 1) + ("DownBlock3D",)))
+        cfg = I2VConfig(in_channels=get("in_channels", 4), out_channels=get("out_channels", 4), block_out_channels=boc,
+                        layers_per_block=get("layers_per_block", 2), cross_attention_dim=get("cross_attention_dim", 1024),
+                        attn_levels=tuple(t.startswith("CrossAttn") for t in down), sample_size=get("sample_size", None))
+    unet = I2VGenXLUNet(cfg).load_state_dict(sd, device=device)
+    shell = HipModule(unet)
+    if hasattr(pipeline, "register_modules"):
+        pipeline.register_modules(unet=shell)        # diffusers' DiffusionPipeline keeps its module registry in sync through this call
+    else:
+        pipeline.unet = shell
+    return unet

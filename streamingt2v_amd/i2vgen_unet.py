@@ -15,12 +15,18 @@ All arithmetic runs in libsvdhip.so; torch is used for buffers and views only.  
   * everything that does not depend on the sample or the timestep (fps embedding, the 145 context tokens and their per-layer
     K / V^T projections, the processed image latents) is computed once per chunk by ``set_conditioning`` and reused by the
     29 DDIM steps -- the reference recomputes it in every forward (unet_i2vgen_xl.py:655-712).
+
+Precision plan (round 5, ops.I2V_EXACT_RIM / ops.I2V_STREAM_F32_MIN_CH; the round-4 plan of video_model.py applied here): the tensors the
+reference's residual additions run on (ResnetBlock2D output, TemporalConvLayer's identity add, the transformers' x + attn(x) / x + ff(x)
+chains and block outputs, the samplers' outputs) stay fp32 BETWEEN kernels -- GEMM epilogues read / write them in fp32, norms read fp32 and
+write the 16-bit operand -- and the rim (conv_in, the embedding MLPs, the image-latent projection, the 4-channel head) runs with split-3
+operands / as the fp32 head kernel.  Only what a matrix core consumes is rounded to 16 bit.
 """
 import torch
 
 from . import ops
 from .params import Spec, check_state_dict
-from .video_model import _dev_bf16, _dev_f32, _spec_ln, pack_conv3x3, pack_geglu, pack_tconv3, pad_rows
+from .video_model import _dev_bf16, _dev_f32, _spec_ln, pack_conv3x3, pack_geglu, pack_tconv3, pack_x3, pad_rows
 
 
 def _pad32(c):
@@ -48,7 +54,7 @@ class I2VConfig:
 
 def _conv(x, w, b, cin_pad, F, H, W, ho=None, wo=None, stride=1, ups=0, **kw):
     ho, wo = ho or H, wo or W
-    return ops.gemm(x, w, bias=b, conv=dict(cin=cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=stride, ups=ups, frames=F), **kw)
+    return ops.gemm(ops.to_elem_rows(x), w, bias=b, conv=dict(cin=cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=stride, ups=ups, frames=F), **kw)
 
 
 class _Resnet:
@@ -79,12 +85,13 @@ class _Resnet:
 
     def forward(self, x, emb_silu, F, Fr, H, W):
         pix = H * W
+        st = ops.i2v_stream_on(self.cout)       # the block output is the residual stream: fp32 between kernels when set (the input is whatever the block before wrote)
         h = ops.groupnorm(x, F, pix, *self.n1, 1e-5, silu=True)
         e = ops.gemm(emb_silu, self.we, bias=self.be, out_f32=True)                       # [B, cout]: one vector per batch element
         h = _conv(h, self.w1, self.b1, self.cin, F, H, W, rowvec=e, rows_per_vec=Fr * pix)
         h = ops.groupnorm(h, F, pix, *self.n2, 1e-5, silu=True)
-        skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
-        return _conv(h, self.w2, self.b2, self.cout, F, H, W, residual=skip)
+        skip = x if self.cin == self.cout else ops.gemm(ops.to_elem_rows(x), self.ws, bias=self.bs, out_f32=st)
+        return _conv(h, self.w2, self.b2, self.cout, F, H, W, residual=skip, out_f32=st)
 
 
 class _TemporalConv:
@@ -111,7 +118,7 @@ class _TemporalConv:
         h = x
         for i, (nw, nb, w, b) in enumerate(self.l):
             h = ops.groupnorm(h, F, pix, nw, nb, 1e-5, frames_per_stat=Fr, silu=True)
-            h = ops.gemm(h, w, bias=b, temporal=tv, residual=x if i == 3 else None)
+            h = ops.gemm(h, w, bias=b, temporal=tv, residual=x if i == 3 else None, out_f32=(i == 3 and ops.i2v_stream_on(self.c)))
         return h
 
 
@@ -181,21 +188,23 @@ class _Transformer2D:
 
     def forward(self, x, F, Fr, H, W):
         c, pix, M = self.c, H * W, F * H * W
-        h = ops.gemm(ops.groupnorm(x, F, pix, *self.n, 1e-6), self.wpi, bias=self.bpi)
+        st = ops.i2v_stream_on(c)               # fp32 residual stream: h and the block output are fp32 between the kernels; every GEMM / attention operand is 16 bit
+        e16 = ops.ELEM if x.dtype == torch.float32 else x.dtype
+        h = ops.gemm(ops.groupnorm(x, F, pix, *self.n, 1e-6), self.wpi, bias=self.bpi, out_f32=st)
         n1 = ops.layernorm(h, *self.ln["norm1"])
         qk = ops.gemm(n1, self.wqk)
-        vt, tok_ld = self._vt_buf(F, pix, x.dtype)
+        vt, tok_ld = self._vt_buf(F, pix, e16)
         ops.gemm(n1, self.wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
-        a = torch.empty((M, c), dtype=x.dtype, device=x.device)
+        a = torch.empty((M, c), dtype=e16, device=x.device)
         ops.attn_spatial(qk[:, :c], qk[:, c:], vt, a, F, pix, self.heads)
-        h = ops.gemm(a, self.wo, bias=self.bo, residual=h)
+        h = ops.gemm(a, self.wo, bias=self.bo, residual=h, out_f32=st)
         k2, vt2, n_ctx = self.kv
         q2 = ops.gemm(ops.layernorm(h, *self.ln["norm2"]), self.wq2)
         ops.attn_cross(q2, k2, vt2, a, F, pix, n_ctx, Fr, self.heads)
-        h = ops.gemm(a, self.wo2, bias=self.bo2, residual=h)
+        h = ops.gemm(a, self.wo2, bias=self.bo2, residual=h, out_f32=st)
         g = ops.gemm(ops.layernorm(h, *self.ln["norm3"]), self.wf1, bias=self.bf1, geglu=True)
-        h = ops.gemm(g, self.wf2, bias=self.bf2, residual=h)
-        return ops.gemm(h, self.wpo, bias=self.bpo, residual=x)
+        h = ops.gemm(g, self.wf2, bias=self.bf2, residual=h)         # x + ff(x) is consumed by proj_out only: a GEMM operand, 16 bit
+        return ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
 
 
 class _TransformerTemporal:
@@ -228,38 +237,48 @@ class _TransformerTemporal:
 
     def forward(self, x, F, Fr, H, W):
         d, pix, M, B = self.d, H * W, F * H * W, F // Fr
-        h = ops.gemm(ops.groupnorm(x, F, pix, *self.n, 1e-6, frames_per_stat=Fr), self.wpi, bias=self.bpi)
-        a = torch.empty((M, d), dtype=x.dtype, device=x.device)
+        st = ops.i2v_stream_on(self.c)
+        e16 = ops.ELEM if x.dtype == torch.float32 else x.dtype
+        h = ops.gemm(ops.groupnorm(x, F, pix, *self.n, 1e-6, frames_per_stat=Fr), self.wpi, bias=self.bpi, out_f32=st)
+        a = torch.empty((M, d), dtype=e16, device=x.device)
         for ln, wqkv, wo, bo in (("norm1", self.wqkv1, self.wo1, self.bo1), ("norm2", self.wqkv2, self.wo2, self.bo2)):
             qkv = ops.gemm(ops.layernorm(h, *self.ln[ln]), wqkv)
             ops.attn_temporal(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, B, Fr, Fr, pix, self.heads)
-            h = ops.gemm(a, wo, bias=bo, residual=h)
+            h = ops.gemm(a, wo, bias=bo, residual=h, out_f32=st)
         g = ops.gemm(ops.layernorm(h, *self.ln["norm3"]), self.wf1, bias=self.bf1, geglu=True)
-        h = ops.gemm(g, self.wf2, bias=self.bf2, residual=h)
-        return ops.gemm(h, self.wpo, bias=self.bpo, residual=x)
+        h = ops.gemm(g, self.wf2, bias=self.bf2, residual=h)         # consumed by proj_out only: 16 bit
+        return ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
 
 
 class _Conv3:
     """plain 3x3 conv with bias (conv_in / downsamplers.0.conv / upsamplers.0.conv / conv_out / image branches)."""
 
-    def __init__(self, p, cin, cout, stride=1, ups=0):
+    def __init__(self, p, cin, cout, stride=1, ups=0, x3=False):
         self.p, self.cin, self.cout, self.stride, self.ups = p, cin, cout, stride, ups
         self.cin_pad, self.cout_pad = _pad32(cin), (cout + 3) // 4 * 4
+        self.x3, self.w3 = x3, None          # a rim convolution: split-3 operands under ops.I2V_EXACT_RIM (at prepare time)
 
     def spec(self, s):
         s.add(self.p + "weight", self.cout, self.cin, 3, 3); s.add(self.p + "bias", self.cout)
 
     def prepare(self, sd, dev):
-        self.w = _dev_bf16(pack_conv3x3(sd[self.p + "weight"], self.cin_pad, self.cout_pad), dev)
+        wp = pack_conv3x3(sd[self.p + "weight"], self.cin_pad, self.cout_pad)
+        self.w = _dev_bf16(wp, dev)
         self.b = _dev_f32(pad_rows(sd[self.p + "bias"].detach().float(), self.cout_pad), dev)
+        self.w3 = pack_x3(wp, 9).to(dev) if (self.x3 and ops.I2V_EXACT_RIM) else None
 
-    def forward(self, x, F, H, W, ho=None, wo=None, **kw):
+    def forward(self, x, F, H, W, ho=None, wo=None, split3=False, **kw):
+        """x: 16-bit or fp32-stream rows [F*H*W, cin_pad]; split3=True: SPLIT-3 rows [F*H*W, 3 * cin_pad] for a rim convolution prepared
+        with split-3 weights (self.w3)."""
         if self.stride == 2:
             ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         elif self.ups:
             ho, wo = ho or 2 * H, wo or 2 * W
         else:
             ho, wo = H, W
+        if split3:
+            assert self.w3 is not None and x.shape[1] == 3 * self.cin_pad
+            return _conv(x, self.w3, self.b, 3 * self.cin_pad, F, H, W, ho, wo, self.stride, self.ups, **kw), ho, wo
         return _conv(x, self.w, self.b, self.cin_pad, F, H, W, ho, wo, self.stride, self.ups, **kw), ho, wo
 
 
@@ -269,10 +288,10 @@ class I2VGenXLUNet:
         boc, L, cd, ic = cfg.block_out_channels, cfg.layers_per_block, cfg.cross_attention_dim, cfg.in_channels
         c0, te = boc[0], boc[0] * 4
         self.temb_ch = te
-        self.conv_in = _Conv3("conv_in.", 2 * ic, c0)
+        self.conv_in = _Conv3("conv_in.", 2 * ic, c0, x3=True)
         self.transformer_in = _TransformerTemporal("transformer_in.", c0, 8)
-        self.il_proj = [_Conv3("image_latents_proj_in.0.", 4, ic * 4), _Conv3("image_latents_proj_in.2.", ic * 4, ic * 4),
-                        _Conv3("image_latents_proj_in.4.", ic * 4, ic)]
+        self.il_proj = [_Conv3("image_latents_proj_in.0.", 4, ic * 4, x3=True), _Conv3("image_latents_proj_in.2.", ic * 4, ic * 4, x3=True),
+                        _Conv3("image_latents_proj_in.4.", ic * 4, ic, x3=True)]
         self.il_ctx = [_Conv3("image_latents_context_embedding.0.", 4, ic * 8),
                        _Conv3("image_latents_context_embedding.3.", ic * 8, ic * 16, stride=2),
                        _Conv3("image_latents_context_embedding.5.", ic * 16, cd, stride=2)]
@@ -359,12 +378,29 @@ class I2VGenXLUNet:
         check_state_dict(self.spec(), sd, prefix)
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if prefix else sd
         self.dev = device
+        # `unet.dtype` / `unet.device` as the pipeline reads them (pipeline_i2vgen_xl.py:265 casts the prompt embeddings to unet.dtype): the dtype of
+        # the weights this mirror was loaded from, so that the swap does not change what the pipeline hands the UNet (found by executing the swap,
+        # tests/test_dropin_enhancer_reference.py)
+        self.dtype = next(iter(sd.values())).dtype
+        self.device = torch.device(device)
         for m in self._modules():
             m.prepare(sd, device)
         W, Fv = (lambda k: _dev_bf16(sd[k], device)), (lambda k: _dev_f32(sd[k], device))
         self.lin = {n: (W(n + ".weight"), Fv(n + ".bias")) for n in ("time_embedding.linear_1", "time_embedding.linear_2", "context_embedding.0",
                                                                     "context_embedding.2", "fps_embedding.0", "fps_embedding.2")}
         self.norm_out = (Fv("conv_norm_out.weight"), Fv("conv_norm_out.bias"))
+        # precision plan (ops.I2V_EXACT_RIM): the time / fps embedding MLPs with split-3 operands (a handful of rows), the head (conv_norm_out + SiLU +
+        # conv_out to 4 channels) as the fp32 kernel svd_head_gn_silu_conv3x3 with weights [tap (ky, kx)][c][4]
+        self.lin3, self.head_wt = {}, None
+        c0, oc = self.cfg.block_out_channels[0], self.cfg.out_channels
+        if ops.I2V_EXACT_RIM:
+            for n in ("time_embedding.linear_1", "time_embedding.linear_2", "fps_embedding.0", "fps_embedding.2"):
+                self.lin3[n] = pack_x3(sd[n + ".weight"], 1).to(device)
+            if oc <= 4 and c0 % 32 == 0:
+                wt = torch.zeros(3, 3, c0, 4, dtype=torch.float32)
+                wt[..., :oc] = sd["conv_out.weight"].detach().float().permute(2, 3, 1, 0)
+                self.head_wt = wt.reshape(9, c0, 4).contiguous().to(device)
+                self.head_b = _dev_f32(pad_rows(sd["conv_out.bias"].detach().float(), 4), device)
         e = "image_latents_temporal_encoder."
         flat = [sd[e + k].detach().float().reshape(-1) for k in ("norm1.weight", "norm1.bias", "attn1.to_q.weight", "attn1.to_k.weight",
                 "attn1.to_v.weight", "attn1.to_out.0.weight", "attn1.to_out.0.bias", "ff.net.0.proj.weight", "ff.net.0.proj.bias",
@@ -380,7 +416,7 @@ class I2VGenXLUNet:
         dev, cd, c0 = self.dev, self.cfg.cross_attention_dim, self.cfg.block_out_channels[0]
         lin = lambda n, x, **kw: ops.gemm(x, self.lin[n][0], bias=self.lin[n][1], **kw)
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
-        fps_emb = lin("fps_embedding.2", lin("fps_embedding.0", ops.timestep_embedding(f32(fps), c0), silu=True), out_f32=True)   # [B, te]
+        fps_emb = self._embed_mlp("fps_embedding.0", "fps_embedding.2", f32(fps), c0)                                         # [B, te] fp32
         # 64 context tokens from the first frame's image latents
         first = f32(image_latents[:, :, 0])
         x = ops.nchw_to_tokens(first, None, None, 32)
@@ -402,15 +438,33 @@ class I2VGenXLUNet:
                 kv.append((m, m.kv))
         # processed image latents (concatenated to every sample)
         il = f32(image_latents.permute(0, 2, 1, 3, 4).reshape(B * Fr, C, H, W))
-        t = ops.nchw_to_tokens(il, None, None, 32)
-        M = t.shape[0]
-        for cv, act in zip(self.il_proj, (True, True, False)):
-            buf = torch.zeros((M, 32), dtype=t.dtype, device=dev)
-            _conv(t, cv.w, cv.b, cv.cin_pad, B * Fr, H, W, silu=act, out=buf[:, : cv.cout_pad])
-            t = buf
+        if self.il_proj[0].w3 is not None:      # precision plan: the projection with split-3 operands, fp32 between its three convolutions
+            t = ops.nchw_to_tokens_x3(il, None, None, 32)
+            M = t.shape[0]
+            for i, (cv, act) in enumerate(zip(self.il_proj, (True, True, False))):
+                buf = torch.zeros((M, 32), dtype=torch.float32, device=dev)
+                _conv(t, cv.w3, cv.b, 3 * cv.cin_pad, B * Fr, H, W, silu=act, out=buf[:, : cv.cout_pad])
+                t = ops.rows_split3(buf) if i < 2 else buf
+        else:
+            t = ops.nchw_to_tokens(il, None, None, 32)
+            M = t.shape[0]
+            for cv, act in zip(self.il_proj, (True, True, False)):
+                buf = torch.zeros((M, 32), dtype=t.dtype, device=dev)
+                _conv(t, cv.w, cv.b, cv.cin_pad, B * Fr, H, W, silu=act, out=buf[:, : cv.cout_pad])
+                t = buf
         il_out = ops.i2v_image_temporal_encoder(t, self.enc_params, B, Fr, H, W)             # fp32 [(b f), 4, H, W]
         self._const = dict(fps_emb=fps_emb, il=il_out, B=B, Fr=Fr, H=H, W=W, kv=kv)
         return self._const
+
+    def _embed_mlp(self, n1, n2, values, dim, rowvec=None):
+        """Timesteps(dim) -> Linear -> SiLU -> Linear (+ rowvec) -> fp32 rows: time_embedding / fps_embedding (unet_i2vgen_xl.py:655-668);
+        split-3 operands under the precision plan."""
+        (w1, b1), (w2, b2) = self.lin[n1], self.lin[n2]
+        if n1 in self.lin3:
+            h = ops.gemm(ops.rows_split3(ops.timestep_embedding(values, dim, f32=True)), self.lin3[n1], bias=b1, silu=True, out_f32=True)
+            return ops.gemm(ops.rows_split3(h), self.lin3[n2], bias=b2, rowvec=rowvec, rows_per_vec=1 if rowvec is not None else 0, out_f32=True)
+        h = ops.gemm(ops.timestep_embedding(values, dim), w1, bias=b1, silu=True)
+        return ops.gemm(h, w2, bias=b2, rowvec=rowvec, rows_per_vec=1 if rowvec is not None else 0, out_f32=True)
 
     def use_conditioning(self, const):
         """Re-install the constants of an earlier set_conditioning call (one per blending window; they do not change over
@@ -428,13 +482,14 @@ class I2VGenXLUNet:
         F = B * Fr
         c0 = self.cfg.block_out_channels[0]
         tt = torch.full((B,), float(timestep), dtype=torch.float32, device=self.dev)
-        h = ops.gemm(ops.timestep_embedding(tt, c0), self.lin["time_embedding.linear_1"][0], bias=self.lin["time_embedding.linear_1"][1], silu=True)
-        emb = ops.gemm(h, self.lin["time_embedding.linear_2"][0], bias=self.lin["time_embedding.linear_2"][1], rowvec=k["fps_emb"],
-                       rows_per_vec=1, out_f32=True)
+        emb = self._embed_mlp("time_embedding.linear_1", "time_embedding.linear_2", tt, c0, rowvec=k["fps_emb"])
         emb_silu = ops.to_elem(emb, silu=True)
 
-        x = ops.nchw_to_tokens(sample_frames, k["il"], None, 32)
-        x, _, _ = self.conv_in.forward(x, F, H, W)
+        st0 = ops.i2v_stream_on(c0)
+        if self.conv_in.w3 is not None:         # precision plan: the 8-channel stem with split-3 operands
+            x, _, _ = self.conv_in.forward(ops.nchw_to_tokens_x3(sample_frames, k["il"], None, 32), F, H, W, split3=True, out_f32=st0)
+        else:
+            x, _, _ = self.conv_in.forward(ops.nchw_to_tokens(sample_frames, k["il"], None, 32), F, H, W, out_f32=st0)
         x = self.transformer_in.forward(x, F, Fr, H, W)
         skips = [(x, H, W)]
         for layers, ds in self.down:
@@ -444,7 +499,7 @@ class I2VGenXLUNet:
                     x = ta.forward(at.forward(x, F, Fr, H, W), F, Fr, H, W)
                 skips.append((x, H, W))
             if ds is not None:
-                x, H, W = ds.forward(x, F, H, W)
+                x, H, W = ds.forward(x, F, H, W, out_f32=ops.i2v_stream_on(ds.cout))      # the samplers' outputs start the next level's stream
                 skips.append((x, H, W))
         r0, t0, at, ta, r1, t1 = self.mid
         x = t0.forward(r0.forward(x, emb_silu, F, Fr, H, W), F, Fr, H, W)
@@ -461,9 +516,12 @@ class I2VGenXLUNet:
             if us is not None:
                 # upsample_size = size of the next skip tensor (unet_i2vgen_xl.py:771-772): odd sizes are one short of 2x
                 _, th, tw = skips[-1]
-                x, H, W = us.forward(x, F, H, W, ho=th, wo=tw)
-        x = ops.groupnorm(x, F, H * W, *self.norm_out, 1e-5, silu=True)
-        x, _, _ = self.conv_out.forward(x, F, H, W)
+                x, H, W = us.forward(x, F, H, W, ho=th, wo=tw, out_f32=ops.i2v_stream_on(us.cout))
+        if self.head_wt is not None:            # conv_norm_out + SiLU + conv_out as one fp32 kernel (precision plan)
+            x = ops.head_gn_silu_conv3x3(x, F, H, W, *self.norm_out, 1e-5, self.head_wt, self.head_b, self.cfg.out_channels)
+        else:
+            x = ops.groupnorm(x, F, H * W, *self.norm_out, 1e-5, silu=True)
+            x, _, _ = self.conv_out.forward(x, F, H, W, out_f32=True)
         return ops.tokens_to_nchw(x, self.cfg.out_channels, F, H, W)
 
     def forward(self, sample, timestep, fps=None, image_latents=None, image_embeddings=None, encoder_hidden_states=None, **_ignored):

@@ -90,6 +90,31 @@ def stream_on(channels, kind=None):
     return m > 0 and channels >= m
 
 
+# ENHANCER PRECISION PLAN (round 5): the same two instruments inside I2VGenXLUNet (i2vgen_unet.py; unet_i2vgen_xl.py:573-814).
+#   I2V_EXACT_RIM          conv_in (8 -> 320 channels), the time / fps embedding MLPs and the three image_latents_proj_in convolutions with split-3
+#                          operands; conv_norm_out + SiLU + conv_out (320 -> 4 channels) as the one fp32 head kernel.  Read at load_state_dict time.
+#   I2V_STREAM_F32_MIN_CH  the fp32 residual stream in every block with at least this many channels (0 = none): ResnetBlock2D output, TemporalConvLayer
+#                          identity add, the transformers' x + attn(x) / x + ff(x) chains and their block outputs, the down / up-sampler outputs.
+#                          Read per forward.
+# Environment overrides for A/B runs: SVD_I2V_EXACT_RIM, SVD_I2V_STREAM_F32_MIN_CH.
+I2V_EXACT_RIM = _os.environ.get("SVD_I2V_EXACT_RIM", "1") != "0"
+I2V_STREAM_F32_MIN_CH = int(_os.environ.get("SVD_I2V_STREAM_F32_MIN_CH", "320"))
+
+
+def set_i2v_precision_plan(exact_rim=None, stream_f32_min_ch=None):
+    """The enhancer's precision plan (None = leave).  exact_rim takes effect at I2VGenXLUNet.load_state_dict (it packs its own weights),
+    stream_f32_min_ch at the next forward."""
+    global I2V_EXACT_RIM, I2V_STREAM_F32_MIN_CH
+    if exact_rim is not None:
+        I2V_EXACT_RIM = bool(exact_rim)
+    if stream_f32_min_ch is not None:
+        I2V_STREAM_F32_MIN_CH = int(stream_f32_min_ch)
+
+
+def i2v_stream_on(channels):
+    return I2V_STREAM_F32_MIN_CH > 0 and channels >= I2V_STREAM_F32_MIN_CH
+
+
 class stream_scope:
     """with stream_scope(True): the fp32 residual stream is on for the networks evaluated inside (ControlNet.forward_tokens)."""
 
@@ -609,10 +634,10 @@ def adaptive_avgpool(x, frames, hin, win, hout, wout):
 
 
 def i2v_image_temporal_encoder(x, params, batch, frames, h, w):
-    """x [(b f) h w, >=4] tokens -> fp32 [(b f), 4, h, w]."""
+    """x [(b f) h w, >=4] tokens (16 bit, or fp32 rows) -> fp32 [(b f), 4, h, w]."""
     assert params.dtype == torch.float32 and params.numel() == 288 and params.is_contiguous()
     out = torch.empty((batch * frames, 4, h, w), dtype=torch.float32, device=x.device)
-    check(_lib.svd_i2v_image_temporal_encoder(_p(x), x.stride(0), _p(params), _p(out), batch, frames, h * w, _dt(x), _stream()),
+    check(_lib.svd_i2v_image_temporal_encoder(_p(x), x.stride(0), _p(params), _p(out), batch, frames, h * w, _dt_in(x), _stream()),
           "svd_i2v_image_temporal_encoder")
     return out
 

@@ -280,9 +280,31 @@ def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
     return x
 
 
+def adaptive_avgpool(x, frames, hin, win, hout, wout):
+    Cc = x.shape[1]
+    y = F.adaptive_avg_pool2d(x.float().view(frames, hin, win, Cc).permute(0, 3, 1, 2), (hout, wout))
+    return y.permute(0, 2, 3, 1).reshape(-1, Cc).to(x.dtype)
+
+
+def i2v_image_temporal_encoder(x, params, batch, frames, h, w):
+    """I2VGenXLTransformerTemporalEncoder on 4-channel rows (b, f, p) (unet_i2vgen_xl.py:110-160): x += to_out(attn(LN(x))) with 2 heads of
+    dim 4 over the frames of a pixel; x += W2 gelu(W1 x + b1) + b2 -> fp32 [(b f), 4, h, w].  Parameter layout: include/svdhip.h."""
+    p = params.float()
+    ln_w, ln_b, wq, wk, wv = p[0:4], p[4:8], p[8:40].view(8, 4), p[40:72].view(8, 4), p[72:104].view(8, 4)
+    wo, bo, w1, b1, w2, b2 = p[104:136].view(4, 8), p[136:140], p[140:204].view(16, 4), p[204:220], p[220:284].view(4, 16), p[284:288]
+    pix = h * w
+    X = x[:, :4].float().view(batch, frames, pix, 4).permute(0, 2, 1, 3)                    # b p f 4
+    n = F.layer_norm(X, (4,), ln_w, ln_b, 1e-5)
+    hd = lambda t: t.view(batch, pix, frames, 2, 4).transpose(2, 3)                         # b p head f 4
+    a = F.scaled_dot_product_attention(hd(n @ wq.t()), hd(n @ wk.t()), hd(n @ wv.t()))
+    xo = X + a.transpose(2, 3).reshape(batch, pix, frames, 8) @ wo.t() + bo
+    xo = xo + F.gelu(xo @ w1.t() + b1) @ w2.t() + b2
+    return xo.permute(0, 2, 3, 1).reshape(batch * frames, 4, h, w).contiguous()
+
+
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
          "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3",
-         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3")
+         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder")
 
 
 def install(monkeypatch=None):
