@@ -286,6 +286,23 @@ int svd_ddim_cfg_step(const float* x, const float* pred_uncond, const float* pre
  * (lib/farancia/libimage/iimage.py:35-36).  Bit-exact with the reference. */
 int svd_frames_to_uint8(const float* X, uint8_t* Y, int32_t frames, int32_t pix, svd_stream_t stream);
 
+/* Fused GEGLU feed-forward of the 320-channel level (ABI v8, round 5):
+ *     Y = [alpha * S + (1 - alpha) *] ( R + b2 + W2 . ( (W1v X + b1v) * gelu_erf(W1g X + b1g) ) )
+ * Replaces the two svd_gemm launches of FeedForward(dim 320, mult 4, glu) -- GEGLU.proj + gate and net[2] (+ the residual add of the
+ * transformer block, + the AlphaBlender of the temporal block): models/svd/sgm/modules/attention.py:94-120,567-593,
+ * models/svd/sgm/modules/video_attention.py:125-168; i2v_enhance/attention.py:414-534 (diffusers FeedForward, activation_fn "geglu").
+ * The [M, hidden] activation never reaches HBM (csrc/ff_fused.hip).
+ *   X  [M][ldx] 16-bit rows (the LayerNorm output), channels == 320.
+ *   Wp packed image of W1 (2*hidden x 320: value rows, then gate rows), b1 (2*hidden) and W2 (320 x hidden):
+ *      svd_ff_fused_pack_bytes(hidden) bytes = hidden/32 chunks of [40 W1 fragments | 64 biases (1 KiB slot) | 20 W2 fragments] in MFMA
+ *      fragment order (streamingt2v_amd/video_model.pack_ff_fused writes it; layout documented in csrc/ff_fused.hip).  hidden % 64 == 0.
+ *   b2 [320] fp32.  R: residual rows or NULL; S: blend partner rows or NULL (alpha ignored then); both fp32 when res_f32 else 16 bit.
+ *   Y  fp32 rows when out_f32, else 16-bit rows.  The hidden activation is rounded to the 16-bit type exactly like the two-launch path. */
+int64_t svd_ff_fused_pack_bytes(int32_t hidden);
+int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t channels, int32_t hidden, const float* b2,
+                       const void* R, int64_t ldr, const void* S, int64_t lds, float alpha, int32_t res_f32,
+                       void* Y, int64_t ldy, int32_t out_f32, int64_t M, int32_t dtype, svd_stream_t stream);
+
 /* Exact-erf GELU in place on 16-bit rows (nn.GELU of the OpenCLIP ViT-H/14 MLP inside FrozenOpenCLIPImageEmbedder,
  * models/svd/sgm/modules/encoders/modules.py:574-732 -> open_clip transformer.py ResidualAttentionBlock.mlp). */
 int svd_gelu_rows(svd_bf16* X, int64_t ldx, int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream);

@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from .params import Spec, check_state_dict
-from .video_model import _dev_bf16, _dev_f32, _spec_ln, pack_conv3x3, pack_geglu, pack_tconv3, pack_x3, pad_rows
+from .video_model import FeedForward, _dev_bf16, _dev_f32, _spec_ln, pack_conv3x3, pack_tconv3, pack_x3, pad_rows
 
 
 def _pad32(c):
@@ -164,9 +164,7 @@ class _Transformer2D:
         self.wv, self.wo, self.bo = W(b + "attn1.to_v.weight"), W(b + "attn1.to_out.0.weight"), Fv(b + "attn1.to_out.0.bias")
         self.wq2, self.wk2, self.wv2 = W(b + "attn2.to_q.weight"), W(b + "attn2.to_k.weight"), W(b + "attn2.to_v.weight")
         self.wo2, self.bo2 = W(b + "attn2.to_out.0.weight"), Fv(b + "attn2.to_out.0.bias")
-        w1, b1 = pack_geglu(g(b + "ff.net.0.proj.weight"), g(b + "ff.net.0.proj.bias"))
-        self.wf1, self.bf1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
-        self.wf2, self.bf2 = W(b + "ff.net.2.weight"), Fv(b + "ff.net.2.bias")
+        self.ff = FeedForward(g, b + "ff.", dev)
 
     def set_context(self, ctx_tok, ctx_pad_tok, B, n_ctx, n_pad):
         """K and V^T of the cross-attention depend only on the context: once per chunk (attention.py:488-501).
@@ -202,8 +200,7 @@ class _Transformer2D:
         q2 = ops.gemm(ops.layernorm(h, *self.ln["norm2"]), self.wq2)
         ops.attn_cross(q2, k2, vt2, a, F, pix, n_ctx, Fr, self.heads)
         h = ops.gemm(a, self.wo2, bias=self.bo2, residual=h, out_f32=st)
-        g = ops.gemm(ops.layernorm(h, *self.ln["norm3"]), self.wf1, bias=self.bf1, geglu=True)
-        h = ops.gemm(g, self.wf2, bias=self.bf2, residual=h)         # x + ff(x) is consumed by proj_out only: a GEMM operand, 16 bit
+        h = self.ff(ops.layernorm(h, *self.ln["norm3"]), residual=h)          # x + ff(x) is consumed by proj_out only: a GEMM operand, 16 bit
         return ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
 
 
@@ -231,9 +228,7 @@ class _TransformerTemporal:
         self.wqkv1, self.wqkv2 = cat3("attn1"), cat3("attn2")
         self.wo1, self.bo1 = W(b + "attn1.to_out.0.weight"), Fv(b + "attn1.to_out.0.bias")
         self.wo2, self.bo2 = W(b + "attn2.to_out.0.weight"), Fv(b + "attn2.to_out.0.bias")
-        w1, b1 = pack_geglu(g(b + "ff.net.0.proj.weight"), g(b + "ff.net.0.proj.bias"))
-        self.wf1, self.bf1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
-        self.wf2, self.bf2 = W(b + "ff.net.2.weight"), Fv(b + "ff.net.2.bias")
+        self.ff = FeedForward(g, b + "ff.", dev)
 
     def forward(self, x, F, Fr, H, W):
         d, pix, M, B = self.d, H * W, F * H * W, F // Fr
@@ -245,8 +240,7 @@ class _TransformerTemporal:
             qkv = ops.gemm(ops.layernorm(h, *self.ln[ln]), wqkv)
             ops.attn_temporal(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, B, Fr, Fr, pix, self.heads)
             h = ops.gemm(a, wo, bias=bo, residual=h, out_f32=st)
-        g = ops.gemm(ops.layernorm(h, *self.ln["norm3"]), self.wf1, bias=self.bf1, geglu=True)
-        h = ops.gemm(g, self.wf2, bias=self.bf2, residual=h)         # consumed by proj_out only: 16 bit
+        h = self.ff(ops.layernorm(h, *self.ln["norm3"]), residual=h)          # consumed by proj_out only: 16 bit
         return ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
 
 

@@ -333,6 +333,46 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
     return out
 
 
+# FUSED FEED-FORWARD (round 5, csrc/ff_fused.hip): LayerNorm output -> GEGLU projection -> gate -> down-projection (+ residual, + blend) in ONE
+# launch for the 320-channel blocks; the [M, 1280] hidden activation never reaches HBM.  SVD_FF_FUSED=0 keeps the two svd_gemm launches (A/B).
+FF_FUSED = _os.environ.get("SVD_FF_FUSED", "1") != "0"
+
+
+def ff_fused_ok(channels, hidden):
+    return FF_FUSED and channels == 320 and hidden % 64 == 0
+
+
+def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None):
+    """x [M, 320] 16-bit rows; img = video_model.pack_ff_fused(...) on the device (uint8); b2 [320] fp32; residual [M, 320] (16 bit or fp32);
+    blend = (alpha, S) like ops.gemm.  Returns residual + b2 + W2 (value * gelu(gate)) [blended], fp32 when out_f32 else 16 bit."""
+    assert x.dtype in (BF16, F16) and x.is_cuda and x.stride(1) == 1 and x.shape[1] == 320 and img.dtype == torch.uint8
+    M, Cc = x.shape
+    r32 = None
+    R = S = None
+    alpha = 0.0
+    if residual is not None:
+        assert residual.dtype in (x.dtype, torch.float32) and residual.stride(1) == 1 and residual.shape == x.shape
+        r32, R = residual.dtype == torch.float32, residual
+    if blend is not None:
+        alpha, S = blend
+        assert R is not None and S.dtype == R.dtype and S.stride(1) == 1 and S.shape == x.shape
+    if out is None:
+        out = torch.empty((M, Cc), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    assert out.shape == (M, Cc) and out.stride(1) == 1 and out.dtype in (torch.float32, x.dtype)
+    flops = 2.0 * M * (2 * hidden) * Cc + 2.0 * M * hidden * Cc
+    nbytes = float(M * Cc * (2 + out.element_size() + (R.element_size() if R is not None else 0) + (S.element_size() if S is not None else 0)) + img.numel())
+    if worklog is not None:
+        _wl("ff_geglu_fused_kernel", flops, nbytes)
+    args = (_p(x), x.stride(0), _p(img), Cc, hidden, _p(b2), _p(R), R.stride(0) if R is not None else 0, _p(S), S.stride(0) if S is not None else 0,
+            float(alpha), int(bool(r32)), _p(out), out.stride(0), int(out.dtype == torch.float32), M, _dt(x), _stream())
+    if trace is not None:
+        with trace.launch("ff_fused_c320", flops=flops, sig=f"ff_M{M}_C{Cc}_H{hidden}_r{int(bool(r32)) if R is not None else 'n'}_o{int(out.dtype == torch.float32)}", nbytes=nbytes):
+            check(_lib.svd_ff_geglu_fused(*args), "svd_ff_geglu_fused")
+        return out
+    check(_lib.svd_ff_geglu_fused(*args), "svd_ff_geglu_fused")
+    return out
+
+
 def attn_spatial(q, k, vt, out, frames, n_tok, heads):
     """q,k: views into a [frames*n_tok, ld] tensor at the head-0 column; vt: [frames, heads*64, tok_ld]."""
     if worklog is not None:

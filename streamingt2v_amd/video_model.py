@@ -66,6 +66,56 @@ def pack_geglu(w, b):
     return torch.stack([wv, wg], 1).reshape(2 * half, K), torch.stack([bv, bg], 1).reshape(2 * half)
 
 
+def pack_ff_fused(w1, b1, w2):
+    """FeedForward(dim 320, GEGLU, mult 4) weights -> the packed image of svd_ff_geglu_fused (csrc/ff_fused.hip), a uint8 tensor.
+    w1 [2 * hidden, C] = GEGLU.proj.weight (rows: value half, then gate half; attention.py:94-101), b1 [2 * hidden], w2 [C, hidden] = net[2].weight.
+    Per chunk of 32 hidden units: 40 W1 fragments (k-step s, tile t: 16 value rows then the 16 gate rows of hidden 32 c + 16 t ..; lane l holds row
+    l % 32, channels 16 s + 8 (l / 32) .. + 7), one 1-KiB slot with the chunk's 64 biases in tile-row order, 20 W2 fragments (tile t, output tile o:
+    lane l holds output channel 32 o + l % 32 and the 8 hidden units its accumulator registers hold: 4 kg + e (e < 4), 8 + 4 kg + e - 4 otherwise)."""
+    C, Hd = w2.shape
+    assert w1.shape == (2 * Hd, C) and b1.shape == (2 * Hd,) and C % 32 == 0 and Hd % 64 == 0
+    nch, NS, NO = Hd // 32, C // 16, C // 32
+    w1, b1, w2 = w1.detach().float().cpu(), b1.detach().float().cpu(), w2.detach().float().cpu()
+    ar = torch.arange
+    c = ar(nch).view(-1, 1, 1, 1, 1); s_ = ar(NS).view(1, -1, 1, 1, 1); t = ar(2).view(1, 1, -1, 1, 1); l = ar(64).view(1, 1, 1, -1, 1); e = ar(8).view(1, 1, 1, 1, -1)
+    m, kg = l & 31, l >> 5
+    hid = 32 * c + 16 * t + (m & 15)
+    row = torch.where(m < 16, hid, Hd + hid)
+    f1 = w1[row, 16 * s_ + 8 * kg + e].to(ops.ELEM).contiguous().view(nch, -1).view(torch.uint8)                  # [nch, 40 KiB]
+    m32 = ar(32).view(1, 1, -1)
+    hb = 32 * ar(nch).view(-1, 1, 1) + 16 * ar(2).view(1, -1, 1) + (m32 & 15)
+    bias = torch.zeros(nch, 256, dtype=torch.float32)
+    bias[:, :64] = b1[torch.where(m32 < 16, hb, Hd + hb)].reshape(nch, 64)
+    t2, o = ar(2).view(1, -1, 1, 1, 1), ar(NO).view(1, 1, -1, 1, 1)                                                # index order [c, t, o, l, e]
+    u = torch.where(e < 4, 4 * kg + e, 8 + 4 * kg + (e - 4))
+    f2 = w2[32 * o + m, 32 * c + 16 * t2 + u].to(ops.ELEM).contiguous().view(nch, -1).view(torch.uint8)           # [nch, 20 KiB]
+    img = torch.cat([f1, bias.view(torch.uint8), f2], 1).contiguous()
+    esz = torch.empty(0, dtype=ops.ELEM).element_size()          # 2 on the device; the CPU host-logic tests run with fp32 "elements" (tests/svd_shim.py)
+    assert img.shape[1] == (2 * NS + 2 * NO) * 512 * esz + 1024
+    return img.view(-1)
+
+
+class FeedForward:
+    """FeedForward(dim, mult 4, glu=True) = GEGLU.proj -> value * gelu(gate) -> net[2] (attention.py:94-120; diffusers FeedForward "geglu" in the
+    enhancer) on the kernel path: ONE launch of svd_ff_geglu_fused where the fused kernel exists (dim 320: the level-0 blocks, whose [M, 1280]
+    hidden tensor is the largest byte-mover of a forward), else the GEGLU-epilogue GEMM followed by the down-projection GEMM.
+    __call__(x_normed, residual=, out_f32=, blend=) -> residual + ff(x) [blended]."""
+
+    def __init__(self, get, prefix, dev):
+        w1r, b1r, w2r = get(prefix + "net.0.proj.weight"), get(prefix + "net.0.proj.bias"), get(prefix + "net.2.weight")
+        w1, b1 = pack_geglu(w1r, b1r)
+        self.w1, self.b1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
+        self.w2, self.b2 = _dev_bf16(w2r, dev), _dev_f32(get(prefix + "net.2.bias"), dev)
+        self.c, self.hidden = w2r.shape
+        self.img = pack_ff_fused(w1r, b1r, w2r).to(dev) if ops.ff_fused_ok(self.c, self.hidden) else None
+
+    def __call__(self, x, residual=None, out_f32=False, blend=None):
+        if self.img is not None and ops.FF_FUSED:
+            return ops.ff_geglu_fused(x, self.img, self.hidden, self.b2, residual=residual, blend=blend, out_f32=out_f32)
+        g = ops.gemm(x, self.w1, bias=self.b1, geglu=True)
+        return ops.gemm(g, self.w2, bias=self.b2, residual=residual, blend=blend, out_f32=out_f32)
+
+
 def pack_x3(w2d, taps):
     """fp32 GEMM weight [N, taps * cin] (K order (tap, c)) -> the SPLIT-3 weight [N, taps * 3 * cin] in the element type: per tap
     [W_hi | W_hi | W_lo] with W_hi = rn16(W), W_lo = rn16(W - W_hi), matching activation rows [A_hi | A_lo | A_hi] (csrc/precision.hip)."""
@@ -269,20 +319,14 @@ class SpatialVideoTransformer:
         self.s_wv = W(b + "attn1.to_v.weight")
         self.s_wo, self.s_bo = W(b + "attn1.to_out.0.weight"), Fv(b + "attn1.to_out.0.bias")
         self.s_wv2, self.s_wo2, self.s_bo2 = W(b + "attn2.to_v.weight"), W(b + "attn2.to_out.0.weight"), Fv(b + "attn2.to_out.0.bias")
-        w1, b1 = pack_geglu(g(b + "ff.net.0.proj.weight"), g(b + "ff.net.0.proj.bias"))
-        self.s_wf1, self.s_bf1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
-        self.s_wf2, self.s_bf2 = W(b + "ff.net.2.weight"), Fv(b + "ff.net.2.bias")
+        self.s_ff = FeedForward(g, b + "ff.", dev)
         t = "time_stack.0."
         self.t_ln = {n: (Fv(t + n + ".weight"), Fv(t + n + ".bias")) for n in ("norm_in", "norm1", "norm3")}
-        w1, b1 = pack_geglu(g(t + "ff_in.net.0.proj.weight"), g(t + "ff_in.net.0.proj.bias"))
-        self.t_wi1, self.t_bi1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
-        self.t_wi2, self.t_bi2 = W(t + "ff_in.net.2.weight"), Fv(t + "ff_in.net.2.bias")
+        self.t_ff_in = FeedForward(g, t + "ff_in.", dev)
         self.t_wqkv = _dev_bf16(torch.cat([g(t + "attn1.to_q.weight"), g(t + "attn1.to_k.weight"), g(t + "attn1.to_v.weight")], 0), dev)
         self.t_wo, self.t_bo = W(t + "attn1.to_out.0.weight"), Fv(t + "attn1.to_out.0.bias")
         self.t_wv2, self.t_wo2, self.t_bo2 = W(t + "attn2.to_v.weight"), W(t + "attn2.to_out.0.weight"), Fv(t + "attn2.to_out.0.bias")
-        w1, b1 = pack_geglu(g(t + "ff.net.0.proj.weight"), g(t + "ff.net.0.proj.bias"))
-        self.t_wf1, self.t_bf1 = _dev_bf16(w1, dev), _dev_f32(b1, dev)
-        self.t_wf2, self.t_bf2 = W(t + "ff.net.2.weight"), Fv(t + "ff.net.2.bias")
+        self.t_ff = FeedForward(g, t + "ff.", dev)
         self.tp_w0, self.tp_b0 = W("time_pos_embed.0.weight"), Fv("time_pos_embed.0.bias")
         self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))
@@ -377,14 +421,12 @@ class SpatialVideoTransformer:
         v2, v2t_c = self._attn2_const(ctx, tctx if tctx_tokens is None else None)                    # attn2 == const/frame
         h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h, out_f32=st)
         n3 = ops.layernorm(h, *self.s_ln["norm3"])
-        g = ops.gemm(n3, self.s_wf1, bias=self.s_bf1, geglu=True)
-        h = ops.gemm(g, self.s_wf2, bias=self.s_bf2, residual=h, out_f32=st)          # x_spatial
+        h = self.s_ff(n3, residual=h, out_f32=st)                                     # x_spatial
         # ---- temporal VideoTransformerBlock on the same token layout (video_attention.py:125-168) ----
         # rows (b, t, pixel) with pt pixels per frame: all of them, or this rank's pixel range of ALL T frames (one all-to-all in)
         ht, pt = (h, pix) if sp is None else (sp.to_pixels(h, B, T, pix), sp.pix_local(pix))
         nin, xm = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=self._time_emb(B * T, T), rows_per_vec=pt, want_sum=True)
-        g = ops.gemm(nin, self.t_wi1, bias=self.t_bi1, geglu=True)
-        xm = ops.gemm(g, self.t_wi2, bias=self.t_bi2, residual=xm, out_f32=st)
+        xm = self.t_ff_in(nin, residual=xm, out_f32=st)
         n1 = ops.layernorm(xm, *self.t_ln["norm1"])
         qkv = ops.gemm(n1, self.t_wqkv)
         at = torch.empty((B * T * pt, c), dtype=e16, device=x.device)
@@ -411,8 +453,7 @@ class SpatialVideoTransformer:
             ops.attn_cross(q2, k2, vt2, a2, B, T * pt, nt, 1, heads)
             xm = ops.gemm(a2, self.t_wo2, bias=self.t_bo2, residual=xm, out_f32=st)
         n3 = ops.layernorm(xm, *self.t_ln["norm3"])
-        g = ops.gemm(n3, self.t_wf1, bias=self.t_bf1, geglu=True)
-        xb = ops.gemm(g, self.t_wf2, bias=self.t_bf2, residual=xm, blend=(self.alpha, ht))     # AlphaBlender
+        xb = self.t_ff(n3, residual=xm, blend=(self.alpha, ht))                                  # AlphaBlender
         if sp is not None:
             xb = sp.to_frames(xb, B, T, pix)                                                    # one all-to-all out
         # xb (the blend) is consumed by proj_out only: a GEMM operand, 16 bit; proj_out + x continues the stream

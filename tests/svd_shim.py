@@ -280,6 +280,52 @@ def edm_euler_step(x, net, guidance_scale, sigma, sigma_next):
     return x
 
 
+def _ff_unpack(img, hidden, C, esize, dtype):
+    """Inverse of video_model.pack_ff_fused, written from the layout documented in csrc/ff_fused.hip / include/svdhip.h: per chunk of 32 hidden
+    units [2 C/16 W1 fragments | 1 KiB bias slot (64 floats) | 2 C/32 W2 fragments]; a fragment = 64 lanes x 8 elements."""
+    nch, NS, NO = hidden // 32, C // 16, C // 32
+    fb = 64 * 8 * esize
+    blob = 2 * NS * fb + 1024 + 2 * NO * fb
+    img = img.cpu().view(nch, blob)
+    f1 = img[:, :2 * NS * fb].contiguous().view(dtype).view(nch, NS, 2, 64, 8).float()
+    bias = img[:, 2 * NS * fb:2 * NS * fb + 256].contiguous().view(torch.float32).view(nch, 2, 32)
+    f2 = img[:, 2 * NS * fb + 1024:].contiguous().view(dtype).view(nch, 2, NO, 64, 8).float()
+    w1 = torch.zeros(2 * hidden, C); b1 = torch.zeros(2 * hidden); w2 = torch.zeros(C, hidden)
+    for c in range(nch):
+        for t in range(2):
+            for l in range(64):
+                m, kg = l & 31, l >> 5
+                hid = 32 * c + 16 * t + (m & 15)
+                row = hid if m < 16 else hidden + hid
+                for s_ in range(NS):
+                    w1[row, 16 * s_ + 8 * kg:16 * s_ + 8 * kg + 8] = f1[c, s_, t, l]
+                for o in range(NO):
+                    for e in range(8):
+                        u = 4 * kg + e if e < 4 else 8 + 4 * kg + (e - 4)
+                        w2[32 * o + m, 32 * c + 16 * t + u] = f2[c, t, o, l, e]
+            for m in range(32):
+                hid = 32 * c + 16 * t + (m & 15)
+                b1[hid if m < 16 else hidden + hid] = bias[c, t, m]
+    return w1, b1, w2
+
+
+def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None):
+    if not hasattr(img, "_ff_unpacked"):          # cached ON the image tensor object (an address can be recycled by another layer's image)
+        img._ff_unpacked = _ff_unpack(img, hidden, x.shape[1], x.element_size(), x.dtype)
+    w1, b1, w2 = img._ff_unpacked
+    y = x.float() @ w1.t() + b1
+    y = (y[:, :hidden] * F.gelu(y[:, hidden:])) @ w2.t() + b2
+    if residual is not None:
+        y = y + residual.float()
+    if blend is not None:
+        alpha, S = blend
+        y = alpha * S.float() + (1.0 - alpha) * y
+    if out is not None:
+        out.copy_(y.to(out.dtype))
+        return out
+    return y if out_f32 else y.to(x.dtype)
+
+
 def adaptive_avgpool(x, frames, hin, win, hout, wout):
     Cc = x.shape[1]
     y = F.adaptive_avg_pool2d(x.float().view(frames, hin, win, Cc).permute(0, 3, 1, 2), (hout, wout))
@@ -304,7 +350,7 @@ def i2v_image_temporal_encoder(x, params, batch, frames, h, w):
 
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
          "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3",
-         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder")
+         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder", "ff_geglu_fused")
 
 
 def install(monkeypatch=None):

@@ -30,14 +30,65 @@ def frame_errors(out, ref):
     return dict(abs_max=e.max().item(), abs_mean=e.mean().item(), rel_max=(e / r).max().item(), ref_rms=r.mean().item(), corr=corr)
 
 
-def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=False, plan=None):
-    """stream_f32: None = the package default (ops.STREAM_F32), True / False = fp32 / 16-bit residual stream.  timing: also time the forward
-    (3 runs after the parity run, device-synchronised) -> res['ms']."""
-    from oracle.cases import FULLSIZE_CASE as c, fullsize_inputs
-    from streamingt2v_amd import ops
+CASES = ("sigma7.47", "s700", "s0p063")          # tests/golden/wrapper_fullsize.pt (round 2) + the two round-5 goldens at the ends of the AYS schedule
+
+
+def _load_nets(sds, device):
+    """the shipped-architecture VideoUNet + ControlNet with the by-name weights of FULLSIZE_CASE (CPU initialisation of 2.27 B parameters takes a
+    minute: `sds` shares it between calls)"""
+    from oracle.cases import FULLSIZE_CASE as c
     from streamingt2v_amd.params import init_by_name
     from streamingt2v_amd.video_model import ControlNet, UNetConfig, VideoUNet
+    cfg = UNetConfig()
+    unet, cn = VideoUNet(cfg), ControlNet(cfg)
+    if "u" not in sds:
+        sds["u"], sds["c"] = init_by_name(unet.spec(), seed=c["seed_unet"]), init_by_name(cn.spec(), seed=c["seed_cn"])
+    unet.load_state_dict(sds["u"], device=device)
+    cn.load_state_dict(sds["c"], device=device)
+    return unet, cn
+
+
+def chunk_fullsize(dtype="fp16", device="cuda", sds=None):
+    """Round 5: sampler o denoiser o guider o StreamingWrapper o VideoDecoder at the shipped size against tests/golden/chunk_fullsize.pt (the
+    reference's own EulerEDMSampler / Denoiser / LinearPredictionGuider / wrapper / decoder: 2 AYS steps sigma 700 -> 0.002 -> 0, decode of the
+    first 8 frames, clamp; oracle/make_golden_fullsize.py --which chunk).  Returns per-frame L2 of the decoded frames (on the golden's pixel
+    subset) and of the latents z."""
+    from oracle.cases import FULLSIZE_CASE as c, FULLSIZE_CHUNK_CASE as cc, fullsize_chunk_inputs, fullsize_pixel_subset
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.sampling import EulerEDMSampler
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VideoDecoder
     from streamingt2v_amd.wrappers import StreamingWrapper
+    torch.set_grad_enabled(False)
+    ops.set_element_dtype(DT[dtype])
+    gold = torch.load(os.path.join(GOLD, "chunk_fullsize.pt"))
+    sds = {} if sds is None else sds
+    unet, cn = _load_nets(sds, device)
+    dec = VideoDecoder()
+    dec.load_state_dict(init_by_name(dec.spec(), seed=35), device=device)
+    inp = fullsize_chunk_inputs()
+    T, n = c["T"], cc["decode_frames"]
+    dev = lambda d: {k: v.to(device) for k, v in d.items()}
+    svd = StreamingSVD(StreamingWrapper(unet, cn, c["Tc"]), AutoencodingEngineDecoder(dec), sampler=EulerEDMSampler(num_steps=cc["steps"], num_frames=T))
+    z = svd.sampler(svd.inference_model, inp["noise"].to(device).clone(), dev(inp["c"]), dev(inp["uc"]), batch_size=2, num_video_frames=T,
+                    ctrl_frames=inp["ctrl_frames"].to(device))
+    frames = svd.decode_first_stage(z[:n], clamp=True)
+    torch.cuda.synchronize()
+    idx = fullsize_pixel_subset(frames.shape[-2] * frames.shape[-1])
+    rf = frame_errors(frames.float().flatten(2)[:, :, idx.to(device)], gold["frames_subset"])
+    rz = frame_errors(z, gold["z"])
+    del unet, cn, dec, svd
+    torch.cuda.empty_cache()
+    ops.set_element_dtype(None)
+    return dict(frames=rf, z=rz)
+
+
+def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=False, plan=None, case="sigma7.47"):
+    """stream_f32: None = the package default (ops.STREAM_F32), True / False = fp32 / 16-bit residual stream.  timing: also time the forward
+    (3 runs after the parity run, device-synchronised) -> res['ms'].  case: which golden / input draw (CASES)."""
+    from oracle.cases import FULLSIZE_CASE as c, fullsize_inputs, fullsize_inputs_sigma
+    from streamingt2v_amd import ops
     torch.set_grad_enabled(False)
     ops.set_element_dtype(DT[dtype])
     prev_stream = ops.STREAM_F32
@@ -45,6 +96,7 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
         ops.set_stream_f32(stream_f32)
     prev_plan = (ops.EXACT_RIM, ops.CN_STREAM_F32, ops.STREAM_F32_MIN_CH)
     prev_kind = dict(ops.STREAM_F32_MIN_CH_KIND)
+    prev_io = ops.STREAM_F32_SVT_IO_MIN_CH
     if plan is not None:              # (exact_rim, cn_stream_f32, stream_f32_min_ch[, per-kind thresholds]): the round-4 precision plan (None = the package default)
         ops.set_precision_plan(*plan[:3])
         ops.STREAM_F32_MIN_CH_KIND.update({"res": None, "svt": None})
@@ -53,16 +105,23 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
             kinds = dict(plan[3])
             ops.STREAM_F32_SVT_IO_MIN_CH = kinds.pop("svt_io", 0)
             ops.STREAM_F32_MIN_CH_KIND.update(kinds)
-    gold = torch.load(os.path.join(GOLD, "wrapper_fullsize.pt"))
-    cfg = UNetConfig()
-    unet, cn = VideoUNet(cfg), ControlNet(cfg)
-    if sds is None:
-        sds = {}
-    if "u" not in sds:             # by-name CPU initialisation of 2.27 B parameters takes a minute: shared between the element types
-        sds["u"], sds["c"] = init_by_name(unet.spec(), seed=c["seed_unet"]), init_by_name(cn.spec(), seed=c["seed_cn"])
-    unet.load_state_dict(sds["u"], device=device)
-    cn.load_state_dict(sds["c"], device=device)
-    inp = {k: v.to(device) for k, v in fullsize_inputs().items()}
+    try:
+        return _wrapper_fullsize(dtype, device, {} if sds is None else sds, timing, case)
+    finally:            # restore the process-wide plan on every path (an OOM in the forward must not leave a sweep's plan set for the next test)
+        ops.set_stream_f32(prev_stream)
+        ops.set_precision_plan(*prev_plan)
+        ops.STREAM_F32_MIN_CH_KIND.update(prev_kind)
+        ops.STREAM_F32_SVT_IO_MIN_CH = prev_io
+        torch.cuda.empty_cache()
+
+
+def _wrapper_fullsize(dtype, device, sds, timing, case):
+    from oracle.cases import FULLSIZE_CASE as c, fullsize_inputs, fullsize_inputs_sigma
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    gold = torch.load(os.path.join(GOLD, "wrapper_fullsize.pt" if case == "sigma7.47" else f"wrapper_fullsize_{case}.pt"))
+    unet, cn = _load_nets(sds, device)
+    inp = {k: v.to(device) for k, v in (fullsize_inputs() if case == "sigma7.47" else fullsize_inputs_sigma(case)).items()}
     T = c["T"]
     wrap = StreamingWrapper(unet, cn, c["Tc"])
     out = wrap.forward(inp["x"], inp["t"], {k: inp[k] for k in ("concat", "crossattn", "vector")}, batch_size=2, num_video_frames=T,
@@ -80,12 +139,8 @@ def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=Fal
                          image_only_indicator=torch.zeros(2, T, device=device), ctrl_frames=inp["ctrl_frames"])
         torch.cuda.synchronize()
         res["ms"] = (time.perf_counter() - t0) / 3 * 1e3
-    ops.set_stream_f32(prev_stream)
-    ops.set_precision_plan(*prev_plan)
-    ops.STREAM_F32_MIN_CH_KIND.update(prev_kind)
-    ops.STREAM_F32_SVT_IO_MIN_CH = 0
+    res["case"] = case
     del unet, cn, wrap
-    torch.cuda.empty_cache()
     return res
 
 
@@ -116,6 +171,8 @@ def main():
     ap.add_argument("--which", default="both")
     ap.add_argument("--stream", default="default", choices=["default", "fp32", "16", "both"], help="residual stream of the wrapper: fp32 / 16 bit / both")
     ap.add_argument("--timing", action="store_true")
+    ap.add_argument("--cases", default="sigma7.47", help="comma-separated subset of " + ",".join(CASES) + " or 'all'")
+    ap.add_argument("--chunk", action="store_true", help="also the 2-step + decode chunk golden (tests/golden/chunk_fullsize.pt)")
     ap.add_argument("--plans", default="default", help="'default' or 'sweep': the round-4 precision plan off / rim + ControlNet stream / + the UNet's fp32 stream at >= 1280, 640, 320 channels")
     a = ap.parse_args()
     plans = [None] if a.plans == "default" else [(False, False, 0), (True, True, 0), (True, True, 1280), (True, True, 640), (True, True, 320)]
@@ -132,12 +189,20 @@ def main():
             print(f"[full-size VideoDecoder 2 frames @576x1024 vs reference, {name}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | "
                   f"rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | corr {r['corr']:.7f}", flush=True)
         if a.which in ("both", "wrapper"):
-            for st, plan in [(st, pl) for st in {"default": [None], "fp32": [True], "16": [False], "both": [True, False]}[a.stream] for pl in plans]:
-                r = wrapper_fullsize(name, sds=sds, stream_f32=st, timing=a.timing, plan=plan)
-                print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, {name}, residual stream {'fp32' if r['stream_f32'] else '16 bit'}, "
+            cases = CASES if a.cases == "all" else tuple(a.cases.split(","))
+            for case, st, plan in [(cs, st, pl) for cs in cases for st in {"default": [None], "fp32": [True], "16": [False], "both": [True, False]}[a.stream] for pl in plans]:
+                if not os.path.exists(os.path.join(GOLD, "wrapper_fullsize.pt" if case == "sigma7.47" else f"wrapper_fullsize_{case}.pt")):
+                    continue
+                r = wrapper_fullsize(name, sds=sds, stream_f32=st, timing=a.timing, plan=plan, case=case)
+                print(f"[full-size StreamingWrapper.forward 2x25 @72x128 vs reference, case {case}, {name}, residual stream {'fp32' if r['stream_f32'] else '16 bit'}, "
                       f"exact rim {'on' if r['plan'][0] else 'off'}, ControlNet stream {'fp32' if r['plan'][1] else '16 bit'}, UNet fp32 stream at >= {r['plan'][2] or 'inf'} channels{(' ' + str(r['plan'][3])) if r['plan'][3] else ''}] "
                       f"per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} | rel max {r['rel_max']:.3e} | ref rms {r['ref_rms']:.3f} | "
                       f"corr {r['corr']:.7f}" + (f" | forward {r['ms']:.1f} ms" if "ms" in r else ""), flush=True)
+        if a.chunk and os.path.exists(os.path.join(GOLD, "chunk_fullsize.pt")):
+            r = chunk_fullsize(name, sds=sds)
+            print(f"[full-size chunk: 2 Euler steps (sigma 700 -> 0.002 -> 0) + decode of 8 frames @576x1024 vs reference, {name}] decoded frames per-frame L2 abs max "
+                  f"{r['frames']['abs_max']:.3e} mean {r['frames']['abs_mean']:.3e} (ref rms {r['frames']['ref_rms']:.3f}, corr {r['frames']['corr']:.7f}) | latents z abs max "
+                  f"{r['z']['abs_max']:.3e} mean {r['z']['abs_mean']:.3e} (ref rms {r['z']['ref_rms']:.3f})", flush=True)
 
 
 if __name__ == "__main__":

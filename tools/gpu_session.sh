@@ -1,6 +1,7 @@
 #!/bin/bash
 # One parametrised lease script (round 4; replaces the per-call r3*.sh files):  gpurun -- 'bash tools/gpu_session.sh <out-dir> <step> [<step> ...]'
 # Every step writes under gpurun_out/<out-dir>/ and is bounded by its own timeout.  Steps:
+#   ffprobe     tools/_bin/ff_fused_probe (round 5: fused feed-forward vs the two-launch path, same process)    i2vparity   tools/i2v_parity.py: enhancer UNet vs the vendored reference per precision plan    paritysigmas   A5 at three sigmas + the 2-step chunk golden
 #   kernels     kernel-level GPU tests (GEMM tiles, norms)                norms       tools/norm_bench.py, packed / one-row LayerNorm and fused / separate GroupNorm finalize
 #   tunear      tools/tune_gemm.py --only ar16 (A/B of kernel variants)      paritysweep   A5 at full size over the precision plans      bench6ab   bench6 with the plan off / default / without the UNet's part
 #   tune        the full tuner (writes streamingt2v_amd/gemm_tiles.json, copied out)
@@ -17,6 +18,10 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
 for step in "$@"; do
   echo "== $step"; t0=$(date +%s)
   case $step in
+    ffprobe)  timeout 400 tools/_bin/ff_fused_probe ${FFPROBE_M:-460800} 20 2>&1 | tee $O/ff_fused_probe.txt ;;
+    i2vparity) timeout 900 python tools/i2v_parity.py --plans ${I2V_PLANS:-sweep} --fullres --timing > $O/i2v_parity.txt 2>$O/i2v_parity.err; cat $O/i2v_parity.txt; tail -3 $O/i2v_parity.err ;;
+    paritysigmas) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --cases all --chunk --timing > $O/fullsize_parity_sigmas.txt 2>$O/parity_sigmas.err; cat $O/fullsize_parity_sigmas.txt; tail -3 $O/parity_sigmas.err
+              timeout 600 python tools/fullsize_parity.py --dtype fp16 --which wrapper --cases all --plans level0io --timing > $O/fullsize_parity_sigmas_level0io.txt 2>$O/parity_sigmas_l0io.err; cat $O/fullsize_parity_sigmas_level0io.txt ;;
     kernels)  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -s -p no:cacheprovider -k "gemm_plain or many_tiles or geglu or implicit_views or groupnorm or layernorm or split3 or x3 or head" > $O/kernels.log 2>&1; grep -E "^\[(rows_split3|x3 conv|head)" $O/kernels.log | head -40; tail -3 $O/kernels.log ;;
     tunear)   timeout 300 python tools/tune_gemm.py --only ar16 --out $O/tiles_ar16.json > $O/tune_ar16.log 2>$O/tune_ar16.err; tail -3 $O/tune_ar16.log ;;
     newtests) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_multiproc.py tests/test_gpu_fullsize.py tests/test_gpu_graph.py -m gpu -q -x -s -p no:cacheprovider > $O/newtests.log 2>&1; grep -E "^\[" $O/newtests.log | grep -v Gloo | cut -c1-260 | head -40; tail -3 $O/newtests.log ;;
