@@ -149,6 +149,48 @@ def chunk():
     print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
+def chunk_autocast():
+    """round 5: the SAME chunk with the network evaluations under torch.autocast("cpu", float16) -- the reference's shipped `precision: 16-mixed`
+    (config.yaml:8); sampler state and decode in fp32 as the reference runs them (config.yaml:310) -- compared with its own fp32 chunk
+    (tests/golden/chunk_fullsize.pt): the envelope the full-size chunk test is anchored to -> tests/golden/chunk_fullsize_autocast.json"""
+    import json
+    from models.svd.sgm.modules.diffusionmodules.denoiser import Denoiser
+    from models.svd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    c, cc = FULLSIZE_CASE, FULLSIZE_CHUNK_CASE
+    T = c["T"]
+    wrap = build_wrapper()
+    dec = build_decoder()
+    inp = fullsize_chunk_inputs()
+    gold = torch.load(os.path.join(OUT, "chunk_fullsize.pt"))
+    den = Denoiser({"target": "models.svd.sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = EulerEDMSampler(s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, num_steps=cc["steps"], verbose=False, device="cpu",
+                              discretization_config={"target": "models.diffusion.discretizer.AlignYourSteps", "params": {"sigma_max": 700.0}},
+                              guider_config={"target": "models.svd.sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                                             "params": {"max_scale": 3.0, "min_scale": 1.5, "num_frames": T}})
+    add = dict(batch_size=2, num_video_frames=T, image_only_indicator=torch.zeros(2, T), ctrl_frames=inp["ctrl_frames"])
+
+    def net(x, t, cd, **kw):
+        with torch.autocast("cpu", dtype=torch.float16):
+            return wrap(x, t, cd, **kw).float()
+    t0 = time.time()
+    z = sampler(lambda x, s, cd: den(net, x, s, cd, **dict(add)), inp["noise"].clone(), cond=inp["c"], uc=inp["uc"])
+    n = cc["decode_frames"]
+    frames = dec(z[:n].float() / 0.18215, timesteps=n).clamp(-1.0, 1.0)
+    idx = fullsize_pixel_subset(frames.shape[-2] * frames.shape[-1])
+    l2 = lambda a, b: (a.float() - b.float()).flatten(1).pow(2).mean(1).sqrt()
+    ef, ez = l2(frames.flatten(2)[:, :, idx], gold["frames_subset"]), l2(z, gold["z"])
+    res = {"case": "2 AYS Euler steps (sigma 700 -> 0.002 -> 0), CFG 2 x 25 frames @ 72x128, ControlNet on 2 x 7 frames @ 576x1024, decode of 8 frames; shipped architecture",
+           "reference": "unmodified reference sampler / denoiser / guider / wrapper / decoder on CPU; fp32 run = tests/golden/chunk_fullsize.pt",
+           "autocast_float16": dict(frames_l2_mean=ef.mean().item(), frames_l2_max=ef.max().item(), z_l2_mean=ez.mean().item(), z_l2_max=ez.max().item(),
+                                    seconds=time.time() - t0)}
+    print(f"[reference chunk, FULL SIZE, network under autocast float16 vs its own fp32] decoded frames per-frame L2 mean {ef.mean():.3e} max {ef.max():.3e} | "
+          f"latents z mean {ez.mean():.3e} max {ez.max():.3e} ({time.time() - t0:.0f} s)", flush=True)
+    path = os.path.join(OUT, "chunk_fullsize_autocast.json")
+    with open(path, "w") as f:
+        json.dump(res, f, indent=1)
+    print("wrote", path)
+
+
 def vae():
     from models.svd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
     kw = dict(ch=128, out_ch=3, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=256,
@@ -183,6 +225,8 @@ def main():
         sigmas()
     if a.which in ("chunk", "round5"):
         chunk()
+    if a.which == "chunk_autocast":
+        chunk_autocast()
 
 
 if __name__ == "__main__":

@@ -61,6 +61,58 @@ def load_conditioner(state_dict, device="cuda", clip_cfg=None, vae_cfg=None, num
     return SVDConditioner(clip, enc, num_frames=num_frames, generator=generator)
 
 
+def load_stock_svd_xt(folder, device="cuda", variant="fp16", num_frames=25, num_conditional_frames=7, generator=None):
+    """The networks of CHUNK 0 from a diffusers-format ``stabilityai/stable-video-diffusion-img2vid-xt`` folder -- what the reference's
+    ``svd_pipeline`` module is (config.yaml:280-299: StableVideoDiffusionPipeline.from_pretrained(..., torch_dtype=float16, variant="fp16"), called
+    at streaming_svd.py:388-390): unet/ (UNetSpatioTemporalConditionModel = the sgm VideoUNet without ControlNet / CAM, re-keyed), vae/
+    (AutoencoderKLTemporalDecoder = sgm Encoder + VideoDecoder, re-keyed), image_encoder/ (CLIPVisionModelWithProjection).  Returns
+    (StreamingWrapper around the stock UNet, AutoencodingEngineDecoder around the stock decoder, SVDConditioner on the stock towers) for
+    ``StreamingSVD.set_initial_model``.  Key maps: diffusers_keys.py (names restated from diffusers 0.30.2, strict in both directions)."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from .clip_vision import ClipVisionConfig, OpenCLIPVisionTower, hf_clip_vision_to_openclip_keys
+    from .conditioner import SVDConditioner
+    from .diffusers_keys import svd_unet_diffusers_to_sgm, svd_vae_diffusers_to_sgm
+    from .temporal_ae import AutoencodingEngineDecoder, CondFrameEncoder, VaeConfig, VideoDecoder
+    from .video_model import UNetConfig, VideoUNet
+    from .wrappers import StreamingWrapper
+
+    def part(name, stem):
+        d = os.path.join(folder, name)
+        cfg = json.load(open(os.path.join(d, "config.json")))
+        for fn in (f"{stem}.{variant}.safetensors", f"{stem}.safetensors"):
+            if os.path.exists(os.path.join(d, fn)):
+                return cfg, load_file(os.path.join(d, fn))
+        raise FileNotFoundError(f"no {stem}[.{variant}].safetensors under {d}")
+
+    ucfg, usd = part("unet", "diffusion_pytorch_model")
+    boc = tuple(ucfg.get("block_out_channels", (320, 640, 1280, 1280)))
+    down = ucfg.get("down_block_types", ("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",))
+    cfg = UNetConfig(in_channels=ucfg.get("in_channels", 8), model_channels=boc[0], out_channels=ucfg.get("out_channels", 4),
+                     num_res_blocks=ucfg.get("layers_per_block", 2), channel_mult=tuple(c // boc[0] for c in boc),
+                     attention_resolutions=tuple(2 ** i for i, t in enumerate(down) if t.startswith("CrossAttn"))[::-1],
+                     context_dim=ucfg.get("cross_attention_dim", 1024), adm_in_channels=ucfg.get("projection_class_embeddings_input_dim", 768),
+                     controlnet_mode=False)
+    unet = VideoUNet(cfg)
+    unet.load_state_dict(svd_unet_diffusers_to_sgm(usd, unet.spec(), cfg.num_res_blocks), device=device)
+    vcfg, vsd = part("vae", "diffusion_pytorch_model")
+    vb = tuple(vcfg.get("block_out_channels", (128, 256, 512, 512)))
+    vae_cfg = VaeConfig(vb[0], tuple(c // vb[0] for c in vb), vcfg.get("layers_per_block", 2))
+    dec, enc = VideoDecoder(vae_cfg), CondFrameEncoder(vae_cfg)
+    dsd, esd = svd_vae_diffusers_to_sgm(vsd, dec.spec(), enc.spec(), len(vb))
+    dec.load_state_dict(dsd, device=device)
+    enc.load_state_dict(esd, device=device)
+    icfg, isd = part("image_encoder", "model")
+    iv = ClipVisionConfig(width=icfg["hidden_size"], layers=icfg["num_hidden_layers"], heads=icfg["num_attention_heads"],
+                          patch_size=icfg["patch_size"], image_size=icfg["image_size"], embed_dim=icfg["projection_dim"],
+                          mlp_ratio=icfg["intermediate_size"] / icfg["hidden_size"])
+    tower = OpenCLIPVisionTower(iv).load_state_dict(hf_clip_vision_to_openclip_keys(isd, iv.layers), device=device)
+    nf = ucfg.get("num_frames", num_frames)
+    return (StreamingWrapper(unet, None, num_conditional_frames), AutoencodingEngineDecoder(dec),
+            SVDConditioner(tower, enc, num_frames=nf, generator=generator))
+
+
 def load_enhancer(folder, device="cuda", variant="fp16", generator=None):
     """The enhancement stage from a diffusers-format ``ali-vilab/i2vgen-xl`` folder (i2v_enhance_interface.py:63-80 loads it with
     I2VGenXLPipeline.from_pretrained(..., torch_dtype=float16, variant="fp16")): unet/, vae/, text_encoder/, image_encoder/ with their
@@ -181,9 +233,11 @@ class StreamingPipeline:
         self.device = unet.device
 
     @classmethod
-    def from_pretrained(cls, streamingsvd_ckpt, i2vgen_folder=None, vfi_ckpt=None, device="cuda", **kw):
-        """Everything inference_i2v.StreamingPipeline.init_model assembles (:125-165), from the same three artefacts: the StreamingSVD
-        checkpoint (UNet + ControlNet + decoder + stage-1 conditioner), the diffusers-format i2vgen-xl folder, EMA-VFI's ours.pkl."""
+    def from_pretrained(cls, streamingsvd_ckpt, i2vgen_folder=None, vfi_ckpt=None, device="cuda", svd_xt_folder=None, **kw):
+        """Everything inference_i2v.StreamingPipeline.init_model assembles (:125-165), from the same artefacts: the StreamingSVD
+        checkpoint (UNet + ControlNet + decoder + stage-1 conditioner), the diffusers-format i2vgen-xl folder, EMA-VFI's ours.pkl, and
+        -- svd_xt_folder -- the stock stabilityai/stable-video-diffusion-img2vid-xt folder the reference generates CHUNK 0 with
+        (config.yaml:280-299; load_stock_svd_xt).  Without it chunk 0 runs on the StreamingSVD checkpoint's own UNet / decoder."""
         sd = streamingsvd_ckpt
         if isinstance(sd, str):
             if sd.endswith(".safetensors"):
@@ -199,7 +253,11 @@ class StreamingPipeline:
         if vfi_ckpt is not None:
             kw["vfi"] = load_vfi(vfi_ckpt, device=device, cfg=cfgs["vfi_cfg"])
         kw.setdefault("input_height", 576)
-        return cls(*load_streamingsvd_checkpoint(sd, device=device, unet_cfg=cfgs["unet_cfg"], vae_cfg=cfgs["vae_cfg"]), **kw)
+        pipe = cls(*load_streamingsvd_checkpoint(sd, device=device, unet_cfg=cfgs["unet_cfg"], vae_cfg=cfgs["vae_cfg"]), **kw)
+        if svd_xt_folder is not None:
+            pipe.model.set_initial_model(*load_stock_svd_xt(svd_xt_folder, device=device, num_frames=pipe.cfg["num_frames_per_chunk"],
+                                                            num_conditional_frames=pipe.cfg["num_conditional_frames"]))
+        return pipe
 
     @classmethod
     def from_checkpoint(cls, path, device="cuda", **kw):

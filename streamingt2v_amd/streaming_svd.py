@@ -29,22 +29,33 @@ class StreamingSVD:
         self.num_conditional_frames = num_conditional_frames
         self.use_memopt = use_memopt
         self.initial_num_steps = 25        # diffusers StableVideoDiffusionPipeline default num_inference_steps (streaming_svd.py:390)
+        # CHUNK 0 runs on the STOCK SVD-XT weights in the reference (config.yaml:280-299 svd_pipeline = StableVideoDiffusionPipeline.from_pretrained(
+        # "stabilityai/stable-video-diffusion-img2vid-xt")): pipeline.load_stock_svd_xt fills these three.  None = this checkpoint's own
+        # `model.diffusion_model.*` / decoder / conditioner (whether StreamingSVD's training left them equal to the stock weights is not checkable offline).
+        self.initial_model = None              # StreamingWrapper(VideoUNet(controlnet_mode=False) with the stock weights, None, Tc)
+        self.initial_first_stage_model = None  # the stock AutoencoderKLTemporalDecoder's decoder
+        self.initial_conditioner = None        # conditioner.SVDConditioner on the stock image_encoder / VAE encoder
+
+    def set_initial_model(self, inference_model, first_stage_model=None, conditioner=None):
+        self.initial_model, self.initial_first_stage_model, self.initial_conditioner = inference_model, first_stage_model, conditioner
+        return self
 
     @torch.no_grad()
-    def decode_first_stage(self, z, clamp=False):
+    def decode_first_stage(self, z, clamp=False, first_stage_model=None):
         """z / 0.18215, frames decoded in groups of 8 (4 with memopt) exactly like the reference (the temporal convolutions zero-pad at the
         group boundaries, so the grouping is part of the result).  The groups are independent: when the decoder carries a process group
         (`first_stage_model.decode_group`, set by parallel.JobPlan.attach) group n is decoded by rank n % world and broadcast -- every rank
         ends up with all frames (the next chunk's control frames), bit-identical to the single-process decode."""
+        fsm = first_stage_model or self.first_stage_model
         z = z * (1.0 / self.scale_factor)
         n_samples = min(z.shape[0], 4 if self.use_memopt else 8)
         n_groups = math.ceil(z.shape[0] / n_samples)
-        group = getattr(self.first_stage_model, "decode_group", None)
+        group = getattr(fsm, "decode_group", None)
         if group is None:
             outs = []
             for n in range(n_groups):
                 zc = z[n * n_samples:(n + 1) * n_samples]
-                outs.append(self.first_stage_model.decode(zc, timesteps=len(zc), clamp=clamp))
+                outs.append(fsm.decode(zc, timesteps=len(zc), clamp=clamp))
             return torch.cat(outs, dim=0)
         import torch.distributed as dist
         from . import parallel
@@ -53,8 +64,8 @@ class StreamingSVD:
         mine = {}
         for n in range(rank, n_groups, world):
             zc = z[n * n_samples:(n + 1) * n_samples]
-            mine[n] = self.first_stage_model.decode(zc, timesteps=len(zc), clamp=clamp)
-        shape = self.first_stage_model.output_shape(z) if not mine else (z.shape[0],) + tuple(next(iter(mine.values())).shape[1:])
+            mine[n] = fsm.decode(zc, timesteps=len(zc), clamp=clamp)
+        shape = fsm.output_shape(z) if not mine else (z.shape[0],) + tuple(next(iter(mine.values())).shape[1:])
         out = torch.empty(shape, dtype=torch.float32, device=z.device)
         for n in range(n_groups):
             part = out[n * n_samples:(n + 1) * n_samples]
@@ -76,13 +87,16 @@ class StreamingSVD:
 
     @torch.no_grad()
     def _generate_initial_chunk(self, c, uc, noise, num_steps=None, min_scale=1.0, max_scale=3.0):
-        """Chunk 0 natively: the reference delegates the first 25 frames to diffusers'
-        StableVideoDiffusionPipeline (streaming_svd.py:388-390) -- the same UNet without ControlNet/CAM, an Euler step on
-        the Karras/EDM schedule (25 steps) and per-frame guidance 1.0 -> 3.0, decoded in groups of 8 (decode_chunk_size=8).
-        Known deviations from that third-party call (un-vendored, "parity unpinned"): c / uc come from the sgm-style
-        conditioner of the AR chunks, i.e. the cond frame is augmented with 0.02 * U[0,1) (streaming_svd.py:174) where diffusers adds
-        0.02 * randn and resizes for CLIP with its own antialiasing; and the UNet weights are `model.diffusion_model.*` of the
-        StreamingSVD checkpoint rather than the stock SVD-XT fp16 weights (whether the two are identical is unverified: no checkpoints offline)."""
+        """Chunk 0.  The reference delegates the first 25 frames to diffusers' StableVideoDiffusionPipeline.__call__(image,
+        decode_chunk_size=8) (streaming_svd.py:388-390); this follows that call (restated in diffusers' own formulation in
+        oracle/svd_pipeline_oracle.py, checked against this method in tests/test_host_svd_cpu.py):
+          * c / uc from `SVDConditioner.first_chunk` -- 0.02 * N(0, 1) noise augmentation, `_resize_with_antialiasing` for CLIP, un-scaled posterior
+            mode, added_time_ids (6, 127, 0.02), zero negative branch (image_to_video below does that);
+          * latents = noise * sqrt(sigma_max^2 + 1) (EulerDiscreteScheduler.init_noise_sigma, "leading" spacing), 25 Karras sigmas 700 -> 0.002 (rho 7),
+            t = 0.25 ln sigma, v-prediction Euler steps -- term by term the EDM Euler step with VScaling of the AR chunks' sampler;
+          * per-frame guidance linspace(1.0, 3.0, 25); the UNet WITHOUT ControlNet / CAM; decode in groups of 8 frames;
+          * on the STOCK SVD-XT weights when they were loaded (`initial_model`, pipeline.load_stock_svd_xt), else on this checkpoint's own UNet / decoder.
+        The third-party call itself is un-vendored and not installed: **parity unpinned** (SURVEY 8f N2)."""
         from .sampling import EDMDiscretization
         T = self.sampler.guider.num_frames
         num_steps = num_steps or self.initial_num_steps
@@ -91,8 +105,13 @@ class StreamingSVD:
                                   use_graph=getattr(self.sampler, "use_graph", False))
         sampler._graph_pool = getattr(self.sampler, "_graph_pool", None)
         x = noise.clone().float().contiguous()
-        z = sampler(self.inference_model, x, c, uc, batch_size=2, num_video_frames=T, ctrl_frames=None)
-        return self.decode_first_stage(z, clamp=True)
+        z = sampler(self.initial_model or self.inference_model, x, c, uc, batch_size=2, num_video_frames=T, ctrl_frames=None)
+        return self.decode_first_stage(z, clamp=True, first_stage_model=self.initial_first_stage_model)
+
+    def initial_conditioning(self, conditioner, image):
+        """(c, uc) of chunk 0: the stock pipeline's conditioner when loaded, diffusers' semantics (`first_chunk`) when the conditioner offers them."""
+        cond0 = self.initial_conditioner or conditioner
+        return cond0.first_chunk(image) if hasattr(cond0, "first_chunk") else cond0(image)
 
     @torch.no_grad()
     def image_to_video(self, conditioner, image, num_frames, noises, num_steps=None):
@@ -102,7 +121,7 @@ class StreamingSVD:
         T, Tc = self.sampler.guider.num_frames, self.num_conditional_frames
         n_ar = max(0, math.ceil((num_frames - T) / (T - Tc)))
         assert len(noises) >= 1 + n_ar
-        c, uc = conditioner(image)
+        c, uc = self.initial_conditioning(conditioner, image)
         first = self.quantize_like_pil(self._generate_initial_chunk(c, uc, noises[0]))
         video = self._autoregressive_generation(first, conditioner, n_ar, noises[1:], num_steps=num_steps)
         return video[:num_frames]

@@ -14,6 +14,20 @@ Tolerance statement (absolute per-frame L2 = RMS error of a frame; values measur
     configuration stays selectable (set_precision_plan(False, False, 0)) and is asserted inside the reference's own fp16-autocast envelope
     (tests/golden/wrapper_fullsize_autocast.json: 1.418e-3 / 1.675e-3, the unmodified reference under torch.autocast(float16), config.yaml:8).
   * bf16 (selectable, not the default): 8x coarser rounding, asserted <= 1.5e-2 / 1e-2.
+Round 5 (profiles/r05_fullsize_parity_sigmas.txt, r05_i2v_parity_plans.txt; goldens from oracle/make_golden_fullsize.py --which round5 and
+oracle/make_golden_i2v_fullarch.py --fullres, the unmodified reference modules on CPU):
+  * row A5 at BOTH ENDS of the AYS schedule on fresh draws (sigma 700: c_noise 1.64, input scaled by 1/700; sigma 0.063: c_noise -0.69) next to the
+    round-2 case (sigma 7.47): worst frame 0.935e-3 / 0.918e-3 / 0.917e-3, mean 0.76-0.78e-3 -> all three asserted <= 1e-3 on every frame.
+  * row A12 (I2VGenXLUNet.forward, the enhancer) under ITS precision plan (ops.I2V_EXACT_RIM, I2V_STREAM_F32_MIN_CH = 320, default): shipped
+    architecture on a 9x16 latent 0.907e-3, and at the SHIPPED latent size 90x160 (N = 14 400 spatial attention) 0.916e-3 max / 0.900e-3 mean ->
+    asserted <= 1e-3 (round 4 without the plan: 1.40e-3, asserted <= 1.8e-3).
+  * rows A1 + A3 + A4 + A5 + A11 composed: 2 Euler steps (sigma 700 -> 0.002 -> 0) of the reference's own sampler / denoiser / guider around the wrapper
+    + decode of 8 frames at 576x1024: decoded frames 1.30e-3 max / 1.22e-3 mean, latents 2.7e-3 / 1.9e-3.  That is the network's per-evaluation
+    deviation (0.76e-3 at sigma 700, where c_out = -1 and the denoised latent IS the network output) multiplied by classifier-free guidance:
+    D = D_u + s (D_c - D_u) carries independent errors of both halves, sqrt(s^2 + (s - 1)^2) = 1.6 .. 3.6 for s = 1.5 .. 3.0 over the 25 frames
+    (mean 2.5 -> 1.9e-3 on the latents, exactly what is measured), and the decoder's contraction.  No 16-bit-operand execution can be closer;
+    the bound asserted is the REFERENCE'S OWN fp16-autocast execution of the same chunk (tests/golden/chunk_fullsize_autocast.json,
+    oracle/make_golden_fullsize.py --which chunk_autocast) and, literally, 1.5e-3 on the decoded frames.
 """
 import pytest
 import torch
@@ -31,8 +45,9 @@ def test_decoder_full_size_vs_reference(dtype):
     assert r["corr"] >= (0.999995 if dtype == "fp16" else 0.9995)
 
 
-@pytest.mark.parametrize("dtype,plan", [("fp16", "default"), ("fp16", "16bit"), ("bf16", "default")])
-def test_streaming_wrapper_full_size_vs_reference(dtype, plan):
+@pytest.mark.parametrize("dtype,plan,case", [("fp16", "default", "sigma7.47"), ("fp16", "default", "s700"), ("fp16", "default", "s0p063"),
+                                             ("fp16", "16bit", "sigma7.47"), ("bf16", "default", "sigma7.47")])
+def test_streaming_wrapper_full_size_vs_reference(dtype, plan, case):
     from streamingt2v_amd import ops
     from tools.fullsize_parity import wrapper_fullsize
     import json
@@ -40,8 +55,8 @@ def test_streaming_wrapper_full_size_vs_reference(dtype, plan):
     # package defaults: fp16 elements, the round-4 precision plan (exact rim + fp32 residual stream in the ControlNet and in every UNet block)
     assert ops.DEFAULT_ELEM == torch.float16 and ops.EXACT_RIM and ops.CN_STREAM_F32 and ops.STREAM_F32_MIN_CH == 320 and not ops.STREAM_F32
     env = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wrapper_fullsize_autocast.json")))["autocast_float16"]
-    r = wrapper_fullsize(dtype, sds=_SDS, plan=None if plan == "default" else (False, False, 0))
-    print(f"[full-size StreamingWrapper.forward vs reference, {dtype}, precision plan {plan}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} "
+    r = wrapper_fullsize(dtype, sds=_SDS, plan=None if plan == "default" else (False, False, 0), case=case)
+    print(f"[full-size StreamingWrapper.forward vs reference, case {case}, {dtype}, precision plan {plan}] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} "
           f"rel {r['rel_max']:.3e} corr {r['corr']:.7f}")
     if dtype == "fp16" and plan == "default":
         assert r["abs_mean"] <= 1e-3 and r["abs_max"] <= 1e-3, r          # north_star: per-frame L2 <= 1e-3, every frame, in the benchmarked configuration
@@ -52,7 +67,34 @@ def test_streaming_wrapper_full_size_vs_reference(dtype, plan):
     else:
         assert r["abs_max"] <= 1.5e-2, r
         assert r["corr"] >= 0.9995
-        _SDS.clear()          # 9 GB of host parameters
+
+
+def test_chunk_full_size_vs_reference():
+    """sampler o denoiser o guider o StreamingWrapper o VideoDecoder at the shipped size on DECODED FRAMES (tests/golden/chunk_fullsize.pt)."""
+    import json
+    import os
+    from tools.fullsize_parity import chunk_fullsize
+    r = chunk_fullsize("fp16", sds=_SDS)
+    _SDS.clear()          # 9 GB of host parameters: the last user of the shared weights
+    f, z = r["frames"], r["z"]
+    print(f"[full-size chunk: 2 Euler steps + decode of 8 frames @576x1024 vs reference, fp16] decoded frames per-frame L2 abs max {f['abs_max']:.3e} mean {f['abs_mean']:.3e} "
+          f"corr {f['corr']:.7f} | latents z abs max {z['abs_max']:.3e} mean {z['abs_mean']:.3e}")
+    assert f["abs_max"] <= 1.5e-3 and z["abs_max"] <= 3.2e-3 and f["corr"] >= 0.99995, r
+    env_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chunk_fullsize_autocast.json")
+    if os.path.exists(env_path):          # the reference's own 16-mixed execution of this chunk: the HIP path must be at least as close to the fp32 run
+        env = json.load(open(env_path))["autocast_float16"]
+        assert f["abs_max"] <= env["frames_l2_max"] and f["abs_mean"] <= env["frames_l2_mean"] and z["abs_max"] <= env["z_l2_max"], (r, env)
+
+
+def test_enhancer_unet_full_resolution_vs_reference():
+    """Row A12 at the SHIPPED latent size: I2VGenXLUNet.forward on CFG 2 x 4 frames @ 90x160 (N = 14 400 spatial attention tokens per frame) against
+    the vendored module's fp32 output (tests/golden/i2v_fullres.pt), under the enhancer's default precision plan."""
+    from streamingt2v_amd import ops
+    from tools.i2v_parity import enhancer_parity
+    assert ops.I2V_EXACT_RIM and ops.I2V_STREAM_F32_MIN_CH == 320
+    r = enhancer_parity(None, fullres=True)
+    print(f"[I2VGenXLUNet.forward 2x4 frames @ 90x160 vs vendored reference, fp16, default plan] per-frame L2 abs max {r['abs_max']:.3e} mean {r['abs_mean']:.3e} rel max {r['rel_max']:.3e}")
+    assert r["abs_max"] <= 1e-3, r
 
 
 def _err(out, ref):
@@ -105,8 +147,9 @@ def test_shipped_architecture_small_latent_vs_reference(dtype, golden_dir):
         print(f"[shipped architecture, small latent, {dtype}] per-frame L2 abs max: StreamingWrapper {e_w:.3e} | VideoUNet (no control) {e_u:.3e} | "
               f"I2VGenXLUNet {e_i2v:.3e} | VideoDecoder {e_dec:.3e} | Encoder {e_enc:.3e}")
         k = 1.0 if f16 else 9.0          # bf16: one rounding is 8x coarser
-        # StreamingWrapper (A5) and VideoUNet without control (A7) under the default precision plan: north_star's 1e-3 (measured 0.76e-3 / 0.69e-3)
-        assert e_w <= 1e-3 * k and e_u <= 1e-3 * k and e_i2v <= 1.8e-3 * k and e_dec <= 1.3e-3 * k and e_enc <= 1.2e-3 * k
+        # StreamingWrapper (A5), VideoUNet without control (A7) and -- round 5 -- I2VGenXLUNet (A12) under their default precision plans: north_star's 1e-3
+        # (measured 0.76e-3 / 0.69e-3 / 0.907e-3)
+        assert e_w <= 1e-3 * k and e_u <= 1e-3 * k and e_i2v <= 1e-3 * k and e_dec <= 1.3e-3 * k and e_enc <= 1.2e-3 * k
     finally:
         ops.set_element_dtype(None)
         torch.cuda.empty_cache()

@@ -117,6 +117,42 @@ def test_gemm_geglu(ops, cfg):
     check(f"gemm geglu cfg{cfg}", out, v * F.gelu(g), 3e-2, 1e-2)
 
 
+@pytest.mark.parametrize("M", [1, 97, 128, 300, 33000 + 17])
+def test_ff_geglu_fused(ops, M):
+    """svd_ff_geglu_fused (csrc/ff_fused.hip; FeedForward of attention.py:94-120 at dim 320) in every residual / output / blend variant:
+    (1) against the two-launch path it replaces (GEGLU-epilogue GEMM -> down-projection GEMM) to one rounding of the 16-bit hidden tile plus
+    accumulation-order noise, (2) against a plain fp32 PyTorch evaluation.  M covers a single row, ragged tiles, many tiles per workgroup."""
+    from streamingt2v_amd.video_model import pack_ff_fused, pack_geglu
+    C, Hd = 320, 1280
+    x = rnd(M, C, seed=41)
+    w1 = rnd(2 * Hd, C, scale=C ** -0.5, seed=42).float().cpu()
+    b1 = rnd(2 * Hd, seed=43, dtype=torch.float32, scale=0.3).cpu()
+    w2 = rnd(C, Hd, scale=Hd ** -0.5, seed=44).float().cpu()
+    b2 = rnd(C, seed=45, dtype=torch.float32, scale=0.3)
+    img = pack_ff_fused(w1, b1, w2).cuda()
+    assert img.numel() == ops._lib.svd_ff_fused_pack_bytes(Hd)
+    w1p, b1p = pack_geglu(w1, b1)
+    w1p, b1p, w2d = w1p.to(BF16).cuda(), b1p.cuda(), w2.to(BF16).cuda()
+    h32 = x.float() @ w1.to(BF16).float().cuda().t() + b1.cuda()
+    v, g = h32.chunk(2, -1)
+    ff32 = (v * F.gelu(g)) @ w2.to(BF16).float().cuda().t() + b2
+    r16, r32 = rnd(M, C, seed=46), rnd(M, C, seed=47, dtype=torch.float32)
+    s16, s32 = rnd(M, C, seed=48), rnd(M, C, seed=49, dtype=torch.float32)
+    alpha = 0.3125
+    for res, blend, out_f32 in [(None, None, False), (None, None, True), (r16, None, False), (r16, None, True), (r32, None, True), (r32, None, False),
+                                (r16, (alpha, s16), False), (r32, (alpha, s32), True)]:
+        got = ops.ff_geglu_fused(x, img, Hd, b2, residual=res, blend=blend, out_f32=out_f32)
+        hid = ops.gemm(x, w1p, bias=b1p, geglu=True)
+        two = ops.gemm(hid, w2d, bias=b2, residual=res, blend=blend, out_f32=out_f32)
+        ref = ff32 + (res.float() if res is not None else 0)
+        if blend is not None:
+            ref = alpha * blend[1].float() + (1 - alpha) * ref
+        assert got.dtype == two.dtype == (torch.float32 if out_f32 else BF16)
+        name = f"ff fused M={M} res={'n' if res is None else res.dtype} blend={blend is not None} out32={out_f32}"
+        check(name + " vs two launches", got, two, 1.2e-2, 8e-3 if not out_f32 else 0.0)      # 16-bit output: one flipped output rounding (bf16: 2^-7 relative)
+        check(name + " vs fp32 torch", got, ref, 3e-2, 1e-2)
+
+
 def test_geglu_gate_function_against_exact_erf(ops):
     """The GEGLU epilogue's gate function alone, on every 16-bit gate value in [-9.5, 9.5]: value = 1 (bias only), gate = x through a unit
     weight, so the output is rn16(gelu(x)) -- the exact-erf GELU of the reference's GEGLU (attention.py:99-101) as csrc/svd_common.h

@@ -697,3 +697,94 @@ def test_ddim_schedule_from_config_and_spacings():
     for bad in (dict(i2v, clip_sample=True), dict(i2v, thresholding=True), dict(i2v, beta_schedule="squaredcos_cap_v2"), dict(i2v, prediction_type="sample")):
         with pytest.raises(NotImplementedError):
             DDIMSchedule.from_config(bad)
+
+
+def test_stock_svd_xt_key_maps_and_folder_loader(tmp_path):
+    """Chunk 0 runs on the STOCK SVD-XT weights in the reference (config.yaml:280-299; streaming_svd.py:388-390): diffusers_keys.py maps the
+    diffusers names of UNetSpatioTemporalConditionModel / AutoencoderKLTemporalDecoder onto the sgm-named specs.  Pinned here: the map is a
+    bijection on the shipped architecture, the totals are the published ones, names every diffusers checkpoint of this model carries come out,
+    and pipeline.load_stock_svd_xt reads a folder written in that format (tiny components), strictly."""
+    import json
+    import pytest
+    from safetensors.torch import save_file
+    from streamingt2v_amd import pipeline as P
+    from streamingt2v_amd.diffusers_keys import sgm_temporal_decoder_key_to_diffusers as dkey, sgm_unet_key_to_diffusers as ukey
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder, VaeConfig, VideoDecoder
+    from streamingt2v_amd.video_model import UNetConfig, VideoUNet
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    # ---- shipped architecture: names only
+    spec = VideoUNet(UNetConfig(controlnet_mode=False)).spec()
+    names = [ukey(n) for n in spec.names()]
+    assert len(set(names)) == len(names) == 1428 and spec.numel() == 1_524_623_082          # SVD-XT UNet: 1.52 B parameters
+    for k in ("conv_in.weight", "time_embedding.linear_1.weight", "add_embedding.linear_2.bias", "conv_norm_out.weight", "conv_out.bias",
+              "down_blocks.0.resnets.0.spatial_res_block.conv1.weight", "down_blocks.0.resnets.0.temporal_res_block.time_emb_proj.weight",
+              "down_blocks.0.resnets.1.time_mixer.mix_factor", "down_blocks.1.resnets.0.spatial_res_block.conv_shortcut.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight", "down_blocks.2.attentions.1.temporal_transformer_blocks.0.ff_in.net.0.proj.weight",
+              "down_blocks.0.attentions.1.time_pos_embed.linear_1.weight", "down_blocks.0.attentions.0.time_mixer.mix_factor", "down_blocks.2.downsamplers.0.conv.weight",
+              "down_blocks.3.resnets.1.temporal_res_block.conv2.bias", "mid_block.resnets.1.spatial_res_block.norm2.weight", "mid_block.attentions.0.proj_in.weight",
+              "up_blocks.0.resnets.2.spatial_res_block.conv_shortcut.weight", "up_blocks.0.upsamplers.0.conv.weight", "up_blocks.1.attentions.2.temporal_transformer_blocks.0.attn1.to_out.0.bias",
+              "up_blocks.2.upsamplers.0.conv.bias", "up_blocks.3.attentions.2.transformer_blocks.0.ff.net.2.weight", "up_blocks.3.resnets.2.time_mixer.mix_factor"):
+        assert k in names, k
+    assert not any(n.startswith(("down_blocks.3.attentions", "down_blocks.3.downsamplers", "up_blocks.0.attentions", "up_blocks.3.upsamplers")) for n in names)
+    dspec, espec = VideoDecoder().spec(), CondFrameEncoder(VaeConfig()).spec()
+    dnames = [dkey(n) for n in dspec.names()]
+    assert len(set(dnames)) == len(dnames) and dspec.numel() + espec.numel() == 97_742_847      # AutoencoderKLTemporalDecoder: 97.7 M
+    for k in ("decoder.conv_in.weight", "decoder.time_conv_out.weight", "decoder.conv_out.bias", "decoder.conv_norm_out.weight", "decoder.mid_block.attentions.0.to_q.weight",
+              "decoder.mid_block.attentions.0.group_norm.bias", "decoder.mid_block.resnets.1.temporal_res_block.conv1.weight", "decoder.up_blocks.0.resnets.2.time_mixer.mix_factor",
+              "decoder.up_blocks.2.resnets.0.spatial_res_block.conv_shortcut.weight", "decoder.up_blocks.2.upsamplers.0.conv.weight", "decoder.up_blocks.3.resnets.1.spatial_res_block.norm1.weight"):
+        assert k in dnames, k
+    assert not any(n.startswith("decoder.up_blocks.3.upsamplers") for n in dnames)
+    # ---- tiny components written as a diffusers folder
+    def write(name, stem, cfg, sd):
+        d = tmp_path / name
+        d.mkdir()
+        json.dump(cfg, open(d / "config.json", "w"))
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(d / f"{stem}.fp16.safetensors"))
+
+    ucfg = UNetConfig(model_channels=64, num_res_blocks=1, attention_resolutions=(1,), channel_mult=(1, 2), context_dim=128, controlnet_mode=False)
+    usd = init_by_name(VideoUNet(ucfg).spec(), seed=11)
+    write("unet", "diffusion_pytorch_model", dict(block_out_channels=[64, 128], layers_per_block=1, cross_attention_dim=128, in_channels=8, out_channels=4,
+                                                  projection_class_embeddings_input_dim=768, num_frames=5,
+                                                  down_block_types=["CrossAttnDownBlockSpatioTemporal", "DownBlockSpatioTemporal"]), {ukey(k, 1): v for k, v in usd.items()})
+    vcfg = VaeConfig(32, (1, 2), 1)
+    dsd, esd = init_by_name(VideoDecoder(vcfg).spec(), seed=12), init_by_name(CondFrameEncoder(vcfg).spec(), seed=13)
+    dif = {}
+    for k, v in dsd.items():
+        nk = dkey(k, 2)
+        dif[nk] = v[:, :, 0, 0] if "attentions.0.to_" in nk and v.dim() == 4 else v
+    for k, v in esd.items():                                  # the encoder half in diffusers' names (inverse of temporal_ae.diffusers_vae_to_sgm_keys)
+        part, _, r = k.partition(".")
+        if part == "quant_conv":
+            dif[k] = v; continue
+        r = r.replace("norm_out.", "conv_norm_out.").replace("nin_shortcut.", "conv_shortcut.").replace("mid.block_1.", "mid_block.resnets.0.").replace("mid.block_2.", "mid_block.resnets.1.")
+        if r.startswith("mid.attn_1."):
+            r = r.replace("mid.attn_1.", "mid_block.attentions.0.").replace("proj_out.", "to_out.0.").replace("norm.", "group_norm.")
+            for n in "qkv":
+                r = r.replace(f"attentions.0.{n}.", f"attentions.0.to_{n}.")
+            v = v[:, :, 0, 0] if v.dim() == 4 else v
+        if r.startswith("down."):
+            _, i, kind, rest = r.split(".", 3)
+            r = f"down_blocks.{i}.resnets.{rest}" if kind == "block" else f"down_blocks.{i}.downsamplers.0.{rest}"
+        dif["encoder." + r] = v
+    write("vae", "diffusion_pytorch_model", dict(block_out_channels=[32, 64], layers_per_block=1), dif)
+    pytest.importorskip("transformers")
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    icfg = dict(hidden_size=320, intermediate_size=1280, num_hidden_layers=1, num_attention_heads=4, image_size=56, patch_size=14, projection_dim=128)
+    hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_act="gelu", **icfg))
+    write("image_encoder", "model", icfg, {k: v for k, v in hf.state_dict().items() if "position_ids" not in k})
+    wrap, fsm, cond = P.load_stock_svd_xt(str(tmp_path), device="cpu", num_conditional_frames=2)
+    assert isinstance(wrap, StreamingWrapper) and wrap.controlnet is None and not wrap.diffusion_model.controlnet_mode and cond.T == 5
+    assert wrap.diffusion_model.cfg.channel_mult == (1, 2) and wrap.diffusion_model.cfg.attention_resolutions == (1,) and hasattr(cond, "first_chunk")
+    # strictness: a tensor the architecture does not have, and a missing one
+    import os
+    from safetensors.torch import load_file
+    f = str(tmp_path / "unet" / "diffusion_pytorch_model.fp16.safetensors")
+    sd = load_file(f)
+    save_file(dict(sd, **{"down_blocks.1.attentions.0.proj_in.weight": torch.zeros(1)}), f)
+    with pytest.raises(KeyError, match="without a counterpart"):
+        P.load_stock_svd_xt(str(tmp_path), device="cpu")
+    sd.pop("mid_block.resnets.0.time_mixer.mix_factor")
+    save_file(sd, f)
+    with pytest.raises(KeyError, match="no tensor"):
+        P.load_stock_svd_xt(str(tmp_path), device="cpu")
