@@ -12,7 +12,7 @@
  *   - stateless, re-entrant, asynchronous on `stream`; no allocation, no host sync inside;
  *   - returns 0 on success, a negative SVD_E* code on bad arguments / launch failure (no exceptions);
  *   - activations are "channels-last token" tensors: row m = (frame, pixel), contiguous channels,
- *     explicit row stride (`ld*`, in elements).  bf16 storage, fp32 accumulation everywhere.
+ *     explicit row stride (`ld*`, in elements).  16-bit storage (fp16 or bf16, per call: `dtype`), fp32 accumulation everywhere.
  */
 #ifndef SVDHIP_H
 #define SVDHIP_H
@@ -26,8 +26,9 @@ extern "C" {
 typedef void* svd_stream_t;      /* hipStream_t */
 typedef uint16_t svd_bf16;       /* raw 16-bit element (bf16 or fp16 bits, see `dtype`) */
 
-/* element type of every 16-bit tensor of a call: bf16 (default, north_star) or fp16 (the reference's own autocast
- * precision, config.yaml:8).  Storage 16 bit, accumulation / statistics fp32 in both.  SVD_DTYPE_F32 only where stated. */
+/* element type of every 16-bit tensor of a call: fp16 -- the reference's own autocast precision (config.yaml:8 "16-mixed"), the host package's
+ * default (ops.DEFAULT_ELEM) and the type every parity bound and bench line is stated in -- or bf16 (what north_star names; same MFMA rate, 8x
+ * coarser rounding; selectable, ops.set_element_dtype).  Storage 16 bit, accumulation / statistics fp32 in both.  SVD_DTYPE_F32 only where stated. */
 enum { SVD_DTYPE_BF16 = 0, SVD_DTYPE_F16 = 1, SVD_DTYPE_F32 = 2 };
 /* OR-ed into the 16-bit `dtype` of the READERS of the fp32 residual stream (svd_groupnorm_stats / _sums / _apply, svd_layernorm,
  * svd_add_rows): the input X (and svd_layernorm's Xsum / svd_add_rows' Y, which continue the stream) is fp32 with leading dimensions in

@@ -86,7 +86,9 @@ def blend_step_units_sharded(latents, predict_half, combine, chunk_size, overlap
     sharding (blend_step_sharded) leaves 5 of 8 GPUs idle; the two CFG halves of a window's UNet evaluation never interact (per-sample norms and
     attention, pipeline_i2vgen_xl.py:851-874: one batched call on cat([latents] * 2)), which makes 2 * n_chunks independent units per DDIM step.
 
-    predict_half(idx, half, window) -> raw UNet prediction of CFG half `half` (0 = unconditional, 1 = text) for window idx, any shape;
+    predict_half(idx, half, window) -> raw UNet prediction of CFG half `half` (0 = unconditional, 1 = text) for window idx.  CONTRACT (asserted
+    on every rank that holds a unit): frames-major [chunk, C, H, W] in the latents' dtype -- a rank WITHOUT a unit (world > 2 * n_chunks) sizes its
+    all-gather buffer from the window alone, and mismatched buffers would hang or corrupt the collective instead of raising;
     combine(idx, window, pred_uncond, pred_text) -> the window after guidance + scheduler step.
     Unit u = 2 * idx + half goes to rank u % world; ONE all-gather of the predictions per step (8.75 MB per unit at the shipped sizes), then
     every rank applies guidance + DDIM (a 9-MB element-wise kernel per window) and the overwrites in window order: all ranks end with the
@@ -99,18 +101,20 @@ def blend_step_units_sharded(latents, predict_half, combine, chunk_size, overlap
     n_units = 2 * n_chunks
     per_rank = (n_units + world - 1) // world
     windows = [latents[:, :, s:s + chunk_size] for s in starts]
-    mine, proto = [], None
+    w0 = windows[0]                                               # prediction of a window [B, C, chunk, H, W]: frames-major [chunk, C, H, W]
+    want = (w0.shape[2], w0.shape[1]) + tuple(w0.shape[3:])
+    mine = []
     for slot in range(per_rank):
         u = slot * world + rank
         if u < n_units:
             p = predict_half(u // 2, u % 2, windows[u // 2]).contiguous()
-            proto = p
+            if tuple(p.shape) != want or p.dtype != latents.dtype:
+                raise ValueError(f"predict_half must return [chunk, C, H, W] = {want} in {latents.dtype} (the all-gather buffers of every rank are "
+                                 f"sized from it), got {tuple(p.shape)} {p.dtype}")
             mine.append(p)
         else:
             mine.append(None)
-    if proto is None:                                             # a rank without any unit (world > 2 * n_chunks) still joins the collective
-        w0 = windows[0]                                           # prediction of a window [B, C, chunk, H, W]: frames-major [chunk, C, H, W]
-        proto = torch.zeros((w0.shape[2], w0.shape[1]) + tuple(w0.shape[3:]), dtype=latents.dtype, device=latents.device)
+    proto = torch.zeros(want, dtype=latents.dtype, device=latents.device)   # ranks without a unit (world > 2 * n_chunks) join the collective with the same buffer
     send = torch.stack([m if m is not None else torch.zeros_like(proto) for m in mine], 0)      # [per_rank, ...]
     recv = [torch.empty_like(send) for _ in range(world)]
     parallel.all_gather(recv, send, group=group)

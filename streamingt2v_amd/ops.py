@@ -49,11 +49,14 @@ def set_stream_f32(on=True):
 #               the UNet's head (7.5 %; GroupNorm + SiLU + conv to 4 channels) run with split-3 (~22-bit) MFMA operands / in fp32 (csrc/precision.hip);
 #   CN_STREAM_F32  the fp32 residual stream INSIDE THE CONTROLNET only (16 % of the squared error for ~1/8 of the stream's bytes: the ControlNet
 #               sees 14 of the 64 frames of a forward and only the encoder half).
-#   STREAM_F32_MIN_CH  the fp32 residual stream in the UNet blocks with at least this many channels (0 = none).  The stream's cost is its bytes: a
-#               level-0 tensor (320 channels @ 72x128) is 295 MB, level 1 147 MB, levels 2 / 3 (1280 channels) 74 / 18 MB -- the low-resolution
-#               half of the blocks carries the stream in fp32 for a fraction of what the whole UNet costs (+7 %).
-# All are package defaults (environment overrides for A/B runs: SVD_EXACT_RIM, SVD_CN_STREAM_F32, SVD_STREAM_F32_MIN_CH); STREAM_F32 (the
-# whole UNet's stream in fp32) stays an option.
+#   STREAM_F32_MIN_CH  the fp32 residual stream in the UNet blocks with at least this many channels (0 = none).  The DEFAULT, 320, equals
+#               model_channels: EVERY block and convolution of the UNet carries the stream in fp32 -- the same as STREAM_F32 = True for the UNet --
+#               at +6.9 % of a forward, because nothing cheaper keeps the worst frame of A5 under 1e-3 (profiles/r04_fullsize_parity_plans.txt:
+#               640 -> 0.940e-3 mean / 1.116e-3 max at +3.6 %; 1280 -> rim + ControlNet stream only, 1.018e-3 / 1.201e-3 at +1.1 %).  The stream's
+#               cost is its bytes: a level-0 tensor (320 channels @ 72x128) is 295 MB, level 1 147 MB, levels 2 / 3 (1280 channels) 74 / 18 MB.
+# All are package defaults (environment overrides for A/B runs: SVD_EXACT_RIM, SVD_CN_STREAM_F32, SVD_STREAM_F32_MIN_CH); STREAM_F32 forces the
+# stream on in every network evaluated (it is what stream_scope sets inside the ControlNet).
+# WHEN THEY TAKE EFFECT: EXACT_RIM at load_state_dict (the rim packs split-3 weights); CN_STREAM_F32 / STREAM_F32_MIN_CH / STREAM_F32 are read per forward.
 import os as _os
 EXACT_RIM = _os.environ.get("SVD_EXACT_RIM", "1") != "0"
 CN_STREAM_F32 = _os.environ.get("SVD_CN_STREAM_F32", "1") != "0"
@@ -66,7 +69,8 @@ for _k in ("res", "svt"):
 
 
 def set_precision_plan(exact_rim=None, cn_stream_f32=None, stream_f32_min_ch=None):
-    """Select the round-4 precision plan (None = leave).  Like set_element_dtype: call BEFORE load_state_dict (the rim packs its own weights)."""
+    """Select the round-4 precision plan (None = leave).  exact_rim takes effect at load_state_dict (the rim packs its own weights: call this
+    BEFORE loading, like set_element_dtype); cn_stream_f32 and stream_f32_min_ch are read at every forward."""
     global EXACT_RIM, CN_STREAM_F32, STREAM_F32_MIN_CH
     if exact_rim is not None:
         EXACT_RIM = bool(exact_rim)

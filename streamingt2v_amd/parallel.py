@@ -29,10 +29,28 @@ def init_from_env(backend=None, device=None):
     return world
 
 
+# CONTROL PLANE.  A host-side gloo group over all ranks, next to the data-path backend: the verdict of the job-plan preflight travels over it
+# (with a timeout), and when that preflight found the data-path backend HUNG inside a collective -- which cannot be cancelled or caught -- the
+# bench's barrier and max-over-ranks move onto it too ("use"), so that the replica fallback still produces its number instead of hanging.
+_CONTROL = {"group": None, "use": False}
+
+
+def control_group(timeout_s=120.0):
+    """Created once, by every rank, in the same place of the program (JobPlan.__init__ with preflight)."""
+    if _CONTROL["group"] is None:
+        import datetime
+        _CONTROL["group"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
+    return _CONTROL["group"]
+
+
 def max_over_ranks(seconds, device="cpu"):
     """Job time = slowest rank (bench contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
+    if _CONTROL["use"]:
+        t = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CONTROL["group"])
+        return t.item()
     t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
@@ -40,7 +58,10 @@ def max_over_ranks(seconds, device="cpu"):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if _CONTROL["use"]:
+            dist.barrier(group=_CONTROL["group"])
+        else:
+            dist.barrier()
 
 
 # ---- collectives ---------------------------------------------------------------------------------------------------------------
@@ -287,58 +308,81 @@ class JobPlan:
             return f"the lowest UNet level has {min_pix} pixels per frame, not divisible by the sequence-parallel degree {sp}"
         return None
 
-    def _preflight(self):
-        """One tiny instance of every collective of the plan on the device the job will use.  Returns None or the failure text."""
+    def _preflight(self, timeout_s=None):
+        """One tiny instance of every collective of the plan on the device the job will use.  Returns None or the failure text.
+
+        The collectives run on a helper thread that is joined with a timeout (SVD_PREFLIGHT_TIMEOUT, default 90 s): a backend that HANGS inside
+        a collective -- which neither raises nor can be cancelled -- is reported like one that throws, and moves the bench's own barrier /
+        max-over-ranks onto the gloo control group (`_CONTROL["use"]`).  The verdict is exchanged over that control group, whose own timeout
+        bounds the wait for a rank that died."""
+        import threading
+        timeout_s = float(os.environ.get("SVD_PREFLIGHT_TIMEOUT", "90")) if timeout_s is None else timeout_s
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        ctl = control_group(timeout_s + 30.0)
+        errs = []
+        th = threading.Thread(target=self._preflight_body, args=(dev, errs), daemon=True, name="svd-preflight")
+        th.start()
+        th.join(timeout_s)
+        hung = th.is_alive()
+        if hung:
+            errs = [f"timed out after {timeout_s:.0f} s inside a collective of the plan (backend {dist.get_backend()} hangs)"] + list(errs)
+        err = "; ".join(errs) if errs else None
+        flag = torch.tensor([0.0 if err is None else 1.0, 1.0 if hung else 0.0])
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl)
+            failed, any_hung = flag[0].item() > 0, flag[1].item() > 0
+        except Exception as e:                      # noqa: BLE001 -- a rank that never arrives (control-plane timeout)
+            failed, any_hung, err = True, True, err or f"control plane: {type(e).__name__}: {e}"
+        if any_hung:
+            _CONTROL["use"] = True
+        if not failed:
+            return None
+        return "job-plan collective preflight failed on " + (f"this rank: {err}" if err else "another rank")
+
+    def _preflight_body(self, dev, errs):
         # Every rank issues EVERY collective of the sequence, in the same order, whatever its local checks say: a rank that stopped at a failed
         # check would leave the others waiting inside the next collective (a mismatched sequence hangs RCCL instead of raising).  Local
-        # failures are only RECORDED here and exchanged by the flag all-reduce below.  (A backend that hangs inside a collective cannot be
-        # caught from here at all: the launcher's timeout is the backstop.)
-        errs = []
+        # failures -- exceptions of the collectives AND of the glue around them (tensor construction, slicing, the final read-back, which can
+        # surface an asynchronous device error) -- are only RECORDED here and exchanged by the flag all-reduce of _preflight.
 
-        def step(what, fn):
+        def step(what, fn, fallback=None):
             try:
                 return fn()
             except Exception as e:                  # noqa: BLE001 -- whatever the backend throws, the job must still produce a number
                 errs.append(f"{what}: {type(e).__name__}: {e}")
-                return None
+                return fallback() if fallback is not None else None
 
         def expect(cond, what):
-            if not cond:
+            ok = step(what, cond)
+            if ok is not None and not ok:
                 errs.append(what)
 
-        net = torch.full((4, 4), float(self.rank), device=dev)
+        if dev.type == "cuda":
+            step("set_device", lambda: torch.cuda.set_device(dev))              # the current device is thread-local
+        net = step("tensor construction", lambda: torch.full((4, 4), float(self.rank), device=dev), lambda: torch.zeros((4, 4)))
         got = step("cfg all-gather", lambda: self.cfg_exchange.gather(net))
-        expect(got is not None and got.shape == (8, 4), "cfg all-gather shape")
+        expect(lambda: got is not None and got.shape == (8, 4), "cfg all-gather shape")
         if self.sp is not None:
             sp, T, pix, C = self.sp, 2 * self.sp.size + 1, 2 * self.sp.size, 8
-            full = torch.arange(T * pix * C, dtype=torch.float32, device=dev).reshape(T * pix, C).to(torch.float16)
-            mine = sp.take_frames(full, 1, T, pix)
+            mk = lambda d: torch.arange(T * pix * C, dtype=torch.float32, device=d).reshape(T * pix, C).to(torch.float16)
+            full = step("tensor construction", lambda: mk(dev), lambda: mk("cpu"))
+            mine = step("take_frames", lambda: sp.take_frames(full, 1, T, pix), lambda: sp.take_frames(mk("cpu"), 1, T, pix))
             px = step("all-to-all (frames -> pixels)", lambda: sp.to_pixels(mine, 1, T, pix))
             if px is None:                              # keep the sequence aligned: the inverse exchange still runs, on a stand-in of the right shape
-                px = torch.zeros((T * sp.pix_local(pix), C), dtype=mine.dtype, device=dev)
+                px = torch.zeros((T * sp.pix_local(pix), C), dtype=mine.dtype, device=mine.device)
             back = step("all-to-all (pixels -> frames)", lambda: sp.to_frames(px, 1, T, pix))
-            expect(back is not None and torch.equal(back, mine), "all-to-all round trip")
+            expect(lambda: back is not None and torch.equal(back, mine), "all-to-all round trip")
             gf = step("padded all-gather", lambda: sp.gather_frames(mine, 1, T, pix))
-            expect(gf is not None and torch.equal(gf, full), "padded all-gather")
-            sums = step("fp64 all-reduce", lambda: sp.allreduce_sums(torch.ones((1, 32, 2), dtype=torch.float64, device=dev)))
-            expect(sums is not None and float(sums[0, 0, 0]) == sp.size, "fp64 all-reduce")
-        t = torch.full((3, 5), float(self.rank), device=dev)
-        src = dist.get_global_rank(self.decode_group, 0)
+            expect(lambda: gf is not None and torch.equal(gf, full), "padded all-gather")
+            ones = step("tensor construction", lambda: torch.ones((1, 32, 2), dtype=torch.float64, device=dev), lambda: torch.ones((1, 32, 2), dtype=torch.float64))
+            sums = step("fp64 all-reduce", lambda: sp.allreduce_sums(ones))
+            expect(lambda: sums is not None and float(sums[0, 0, 0]) == sp.size, "fp64 all-reduce")
+        t = step("tensor construction", lambda: torch.full((3, 5), float(self.rank), device=dev), lambda: torch.full((3, 5), float(self.rank)))
+        src = step("get_global_rank", lambda: dist.get_global_rank(self.decode_group, 0), lambda: 0)
         step("broadcast", lambda: broadcast(t, src=src, group=self.decode_group))
         if dev.type == "cuda":
             step("synchronize", torch.cuda.synchronize)
-        expect(float(t[0, 0]) == float(src), "broadcast")
-        err = "; ".join(errs) if errs else None
-        flag = torch.tensor([0.0 if err is None else 1.0], device="cpu" if dist.get_backend() == "gloo" else dev)
-        try:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            failed = flag.item() > 0
-        except Exception as e:                      # noqa: BLE001
-            failed, err = True, err or f"{type(e).__name__}: {e}"
-        if not failed:
-            return None
-        return "job-plan collective preflight failed on " + (f"this rank: {err}" if err else "another rank")
+        expect(lambda: float(t[0, 0]) == float(src), "broadcast")
 
     @classmethod
     def from_env(cls, world, mode, **kw):

@@ -533,21 +533,25 @@ class _Conv:
         self.b = _dev_f32(pad_rows(sd[self.p + "bias"].detach().float(), self.cout_pad), dev)
         self.w3 = pack_x3(wp, 9).to(dev) if (self.x3 and ops.EXACT_RIM) else None
 
-    def forward(self, x, F, H, W, **kw):
-        """x: 16-bit (or fp32-stream) rows [F*H*W, cin_pad]; a rim convolution (w3) also takes SPLIT-3 rows [F*H*W, 3*cin_pad] (ops.rows_split3 /
-        ops.nchw_to_tokens_x3) or fp32 rows, which it splits itself."""
+    def forward(self, x, F, H, W, split3=False, **kw):
+        """x: 16-bit (or fp32-stream) rows [F*H*W, cin_pad].  A rim convolution (w3) takes SPLIT-3 rows [F*H*W, 3*cin_pad] (ops.rows_split3 /
+        ops.nchw_to_tokens_x3) when the caller SAYS so (split3=True: the layout is never inferred from the column count), or fp32 rows, which it
+        splits itself."""
         if self.stride == 2:
             ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         elif self.ups:
             ho, wo = 2 * H, 2 * W
         else:
             ho, wo = H, W
-        if self.w3 is not None and (x.shape[1] == 3 * self.cin_pad or x.dtype == torch.float32):
-            if x.shape[1] != 3 * self.cin_pad:
+        assert not split3 or (self.w3 is not None and x.shape[1] == 3 * self.cin_pad and x.dtype != torch.float32), \
+            "split-3 rows handed to a convolution prepared without the rim weights (ops.EXACT_RIM at load time) or of the wrong width"
+        if self.w3 is not None and (split3 or x.dtype == torch.float32):
+            if not split3:
+                assert x.shape[1] == self.cin_pad
                 x = ops.rows_split3(x)
             cv = dict(cin=3 * self.cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=self.stride, ups=self.ups, frames=F)
             return ops.gemm(x, self.w3, bias=self.b, conv=cv, **kw), ho, wo
-        assert x.shape[1] == self.cin_pad or self.w3 is None, "split-3 rows handed to a convolution prepared without the rim weights"
+        assert x.shape[1] == self.cin_pad, f"{self.p}: rows of {x.shape[1]} columns, expected {self.cin_pad}"
         cv = dict(cin=self.cin_pad, hin=H, win=W, hout=ho, wout=wo, stride=self.stride, ups=self.ups, frames=F)
         return ops.gemm(ops.to_elem_rows(x), self.w, bias=self.b, conv=cv, **kw), ho, wo
 
@@ -688,7 +692,8 @@ class _EncoderBase:
             elif isinstance(m, SpatialVideoTransformer):
                 h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp)
             else:
-                h, H, W = m.forward(h, F, H, W, out_f32=ops.stream_on(m.cout))      # stem / Downsample / Upsample convolutions write the stream
+                # stem / Downsample / Upsample convolutions write the stream; a rim stem (w3) is fed the split-3 rows of input_tokens()
+                h, H, W = m.forward(h, F, H, W, split3=m.w3 is not None and h.dtype != torch.float32, out_f32=ops.stream_on(m.cout))
         return h, H, W
 
     def _local_conditioning(self, timesteps, context, y, T, sp):
@@ -883,12 +888,12 @@ class ControlNetConditioningEmbedding:
             # precision plan (ops.EXACT_RIM): the whole embedding with split-3 operands, fp32 between the layers, LayerNorm + SiLU in fp32.
             # It runs once per chunk (ControlNet.embed_condition) and carries 15 % of the forward's squared 16-bit error when run in 16 bit.
             s3 = ops.nchw_to_tokens_x3(cond_nchw.float().contiguous(), None, None, 32)
-            h, H, W = self.conv_in.forward(s3, Fc, H, W, silu=True, out_f32=True)
+            h, H, W = self.conv_in.forward(s3, Fc, H, W, split3=True, silu=True, out_f32=True)
             s3 = ops.rows_split3(h)
             for b, (nw, nb) in zip(self.blocks, self.norms):
-                h, H, W = b.forward(s3, Fc, H, W, out_f32=True)
+                h, H, W = b.forward(s3, Fc, H, W, split3=True, out_f32=True)
                 s3 = ops.rows_split3(h, ln=(nw, nb), silu=True)
-            h, H, W = self.conv_out.forward(s3, Fc, H, W, out_f32=True)
+            h, H, W = self.conv_out.forward(s3, Fc, H, W, split3=True, out_f32=True)
             return h, H, W                       # fp32 rows: added to the stem output by svd_add_rows_bf32
         h = ops.nchw_to_tokens(cond_nchw.float().contiguous(), None, None, 32)
         h, H, W = self.conv_in.forward(h, Fc, H, W, silu=True)

@@ -259,3 +259,43 @@ def test_sequence_parallel_forward_equals_single_process(world):
         assert e_job < 2e-4, (rank, e_job)
         assert dec_ok and scaling == "strong"
         assert ("sequence parallelism of degree %d" % (world // 2)) in desc or world == 2
+
+
+# ---- a data-path backend that HANGS inside a collective: the preflight times out, the plan falls back to replicas, the bench's barrier moves ----
+
+def _hang_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), SVD_PREFLIGHT_TIMEOUT="4")
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from streamingt2v_amd import parallel
+    assert parallel.init_from_env(backend="gloo") == world
+    real = parallel.CfgPairExchange.gather
+    if rank == 1:                                       # rank 1 never enters the first collective of the plan: rank 0 blocks inside it for good
+        parallel.CfgPairExchange.gather = lambda self, x: time.sleep(3600)
+    t0 = time.perf_counter()
+    plan = parallel.JobPlan(world, rank, "pairs")
+    dt = time.perf_counter() - t0
+    parallel.CfgPairExchange.gather = real
+    parallel.barrier()                                  # must not touch the hung default group
+    slowest = parallel.max_over_ranks(float(rank + 1))
+    out.put((rank, plan.mode, plan.fallback_reason, plan.n_videos, plan.video_id, parallel._CONTROL["use"], slowest, dt))
+    out.close(); out.join_thread()
+    os._exit(0)                                         # the helper threads are parked inside the dead collective: no orderly teardown
+
+
+def test_preflight_times_out_on_a_hung_backend_and_falls_back_to_replicas():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hang_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, mode, why, n_videos, video_id, use_ctl, slowest, dt in res:
+        assert mode == "replica" and n_videos == 2 and video_id == rank, (rank, mode)
+        assert why is not None and "preflight failed" in why and use_ctl, (rank, why)
+        assert slowest == 2.0 and dt < 60.0, (rank, slowest, dt)
+    assert any("timed out" in r[2] for r in res)

@@ -148,3 +148,73 @@ def test_apm_block_host_logic_vs_reference_golden(monkeypatch, golden_dir):
     ctx1, tctx1 = ops.to_bf16(one[:, 0].contiguous()), ops.to_bf16(one[::T, 0].contiguous())
     with torch.no_grad():
         assert torch.equal(svt.forward(tok, ctx1, tctx1, Fr, T, H, W), plain.forward(tok, ctx1, tctx1, Fr, T, H, W))
+
+
+def test_initial_chunk_follows_the_diffusers_pipeline(monkeypatch):
+    """Row N2: chunk 0 as the reference computes it -- diffusers' StableVideoDiffusionPipeline.__call__(image, decode_chunk_size=8)
+    (streaming_svd.py:388-394) -- restated IN DIFFUSERS' OWN FORMULATION in oracle/svd_pipeline_oracle.py (EulerDiscreteScheduler with Karras sigmas
+    from a float64 numpy ramp, scale_model_input, v-prediction pred_original_sample, init_noise_sigma, guidance linspace(1, 3), 0.02 * randn
+    augmentation, `_resize_with_antialiasing`, un-scaled image latents, uint8 PIL frames) against the product's path in ITS formulation:
+    SVDConditioner.first_chunk -> StreamingSVD._generate_initial_chunk (EDM sampler with VScaling, fused step) -> quantize_like_pil, with the
+    stock-weights slot (`set_initial_model`) in use.  fp32 on both sides (shim launchers): latents to rounding, frames to one uint8 level."""
+    svd_shim.install(monkeypatch)
+    from oracle import cases, svd_oracle as O, svd_pipeline_oracle as PO
+    from streamingt2v_amd.conditioner import SVDConditioner
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.sampling import EulerEDMSampler
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VaeConfig, VideoDecoder
+    from streamingt2v_amd.video_model import UNetConfig, VideoUNet
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    tu, tv = cases.TINY_UNET, cases.TINY_VAE
+    T, h, w, steps = 5, 8, 8, 4
+    ucfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"], channel_mult=tu["channel_mult"], controlnet_mode=False)
+    unet = VideoUNet(ucfg)
+    sd_u = init_by_name(unet.spec(), seed=21)
+    unet.load_state_dict(sd_u, device="cpu")
+    dec = VideoDecoder(VaeConfig(tv["ch"], tv["ch_mult"], tv["num_res_blocks"]))
+    sd_d = init_by_name(dec.spec(), seed=22)
+    dec.load_state_dict(sd_d, device="cpu")
+    ocfg = O.Cfg(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"], channel_mult=tu["channel_mult"])
+    vcfg = O.VaeCfg(tv["ch"], tv["ch_mult"], tv["num_res_blocks"])
+    up = 2 ** (len(tv["ch_mult"]) - 1)
+    g = torch.Generator().manual_seed(77)
+    image01 = torch.rand(1, 3, 8 * h, 8 * w, generator=g)                       # "the PIL image"
+    aug = torch.randn(1, 3, 8 * h, 8 * w, generator=g)
+    lat = torch.randn(1, T, 4, h, w, generator=g)
+    # ---- the product: a StreamingSVD whose own networks must NOT be touched for chunk 0 once the stock slot is filled
+    class Boom:
+        def __getattr__(self, k):
+            raise AssertionError("chunk 0 must run on the stock-weights slot")
+    svd = StreamingSVD(Boom(), Boom(), EulerEDMSampler(num_steps=30, num_frames=T), num_conditional_frames=tu["Tc"])
+    svd.initial_num_steps = steps
+    cond = SVDConditioner(cases.fake_clip_embed, cases.fake_cond_encode, num_frames=T)
+    svd.set_initial_model(StreamingWrapper(unet, None, tu["Tc"]), AutoencodingEngineDecoder(dec), cond)
+    with torch.no_grad():
+        c, uc = svd.initial_conditioning(None, image01[0] * 2 - 1)              # draws 0.02 * randn itself ...
+        c2, uc2 = cond.first_chunk(image01[0] * 2 - 1, aug_noise=aug)           # ... here with the oracle's draw
+        assert c["concat"].shape == c2["concat"].shape and not torch.equal(c["concat"], c2["concat"]) and torch.equal(c["crossattn"], c2["crossattn"])
+        frames = svd.quantize_like_pil(svd._generate_initial_chunk(c2, uc2, lat[0]))
+        z_prod = EulerEDMSampler(num_steps=steps, num_frames=T, min_scale=1.0, max_scale=3.0,
+                                 discretization=__import__("streamingt2v_amd.sampling", fromlist=["x"]).EDMDiscretization())(
+            svd.initial_model, lat[0].clone(), c2, uc2, batch_size=2, num_video_frames=T, ctrl_frames=None)
+        # ---- diffusers' formulation on the oracle networks
+        unet_d = PO.sgm_unet_as_diffusers(lambda x, t, ctx, y: O.video_unet(sd_u, ocfg, x, t, ctx, y, T), T)
+        u8, z_ref = PO.svd_pipeline_call(image01, cases.fake_clip_embed, cases.fake_cond_encode, unet_d,
+                                         lambda z, num_frames: O.video_decoder(sd_d, vcfg, z, num_frames), aug_noise=aug, latents=lat,
+                                         num_frames=T, num_inference_steps=steps, decode_chunk_size=8)
+    ref = PO.frames_back_to_float(u8)
+    assert frames.shape == ref.shape == (T, 3, up * h, up * w)
+    ez = (z_prod - z_ref[0]).abs().max().item() / z_ref.abs().max().item()
+    lv = ((frames - ref).abs() * 127.5).round()
+    print(f"[chunk 0 vs the diffusers-formulation oracle] latents max rel err {ez:.2e}; uint8 frames: {100 * (lv > 0).float().mean():.3f} % of bytes differ, max {int(lv.max())} level")
+    assert ez < 2e-4, ez
+    assert lv.max().item() <= 1 and (lv > 0).float().mean().item() < 5e-3
+    # the CLIP resize of chunk 0 is diffusers' always-blurring copy of kornia's: identical on a down-scale, and when nothing shrinks its sigma of
+    # 0.001 makes the 3-tap blur an identity
+    x = torch.rand(1, 3, 300, 500, generator=g) * 2 - 1
+    assert torch.allclose(SVDConditioner.clip_preprocess(x, always_blur=True), SVDConditioner.clip_preprocess(x), atol=1e-6)
+    from streamingt2v_amd.conditioner import kornia_resize_antialias
+    small = torch.rand(1, 3, 100, 100, generator=g)
+    assert torch.allclose(kornia_resize_antialias(small, (224, 224), always_blur=True), PO.resize_with_antialiasing(small, (224, 224)), atol=1e-6)
+    assert torch.allclose(kornia_resize_antialias(small, (224, 224)), PO.resize_with_antialiasing(small, (224, 224)), atol=1e-6)
