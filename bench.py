@@ -214,6 +214,9 @@ def cpu_baseline(workload):
         enh_s = 29 * win_fwd * (3 + 3 / 38)
         stage1_s = (25 * fwd_c2 + dec_chunk) + 5 * (30 * fwd_ar + dec_chunk)
         return {"value": 180 / (stage1_s + enh_s), "unit": "frames/s", "cores": cores, "kind": "port",
+                "reference_modules_8core_s": {"streaming_wrapper_forward_cfg2x25": 553.0, "video_decoder_per_frame": 28.0,
+                                              "note": "the reference's OWN unmodified modules, fp32, timed once on the 8-core build container (profiles/r02_cpu_reference_forward.txt); "
+                                                      "static: /root/reference does not exist on the GPU box"},
                 "sample": f"stage 1: oracle VideoUNet forward, CFG 2 x {T} frames @ {h}x{w} latent: {t_unet:.1f} s; VideoDecoder 1 frame @ 576x1024: {t_dec:.1f} s "
                           f"=> {stage1_s:.0f} s per 100-frame stage 1; enhancement: oracle I2VGenXLUNet forward, CFG 2 x {Fe} frames @ {he}x{we} latent: {t_enh:.1f} s; "
                           f"x19 over frames => {win_fwd:.0f} s per 38-frame window forward, x 29 DDIM steps x (3 windows + key-frame pre-pass) => {enh_s:.0f} s; "
@@ -225,6 +228,9 @@ def cpu_baseline(workload):
     else:
         chunk_s, frames, what = (25 * fwd_c2 + dec_chunk) + 5 * (30 * fwd_ar + dec_chunk), 100, "100-frame stage 1 (chunk 0 + 5 AR chunks)"
     return {"value": frames / chunk_s, "unit": "frames/s", "cores": cores, "kind": "port",
+            "reference_modules_8core_s": {"streaming_wrapper_forward_cfg2x25": 553.0, "video_decoder_per_frame": 28.0,
+                                          "note": "the reference's OWN unmodified modules, fp32, timed once on the 8-core build container (profiles/r02_cpu_reference_forward.txt); "
+                                                  "static: /root/reference does not exist on the GPU box"},
             "sample": f"oracle VideoUNet forward, CFG 2 x {T} frames @ {h}x{w} latent (full size): {t_unet:.1f} s; VideoDecoder 1 frame @ 576x1024: "
                       f"{t_dec:.1f} s; x12.5 over frames => {fwd_c2:.0f} s per 50-frame forward (x1.138 with ControlNet + CAM), "
                       f"{dec_chunk:.0f} s per 25-frame decode => {chunk_s:.0f} s per {what}"}
@@ -508,9 +514,11 @@ def run_full(args, rank, world, device):
     pipe = P.StreamingPipeline.__new__(P.StreamingPipeline)          # the stages are wired by hand: no checkpoint to load offline
     pipe.cfg = dict(P.DEFAULTS, enhance_steps=args.denoise_steps or P.DEFAULTS["enhance_steps"])
     pipe.model, pipe.enhancer_unet, pipe.vfi, pipe.device = model, eunet, vfi, device
-    pipe.group = None
+    pipe.group = pipe.plan = None
     if world > 1 and plan.mode in ("job", "pairs"):
         pipe.group = plan.decode_group          # job: all ranks; pairs: the two ranks of this video
+        if plan.mode == "job" and plan.sp is not None and plan.sp.size in (2, 4, 8):
+            pipe.plan = plan                    # enhancer: CFG pair x frame<->pixel sequence parallelism (the 90x160 .. 12x20 levels split over 2 / 4 / 8 ranks)
     ge = torch.Generator(); ge.manual_seed(1)
     prompt = (torch.randn(1, 77, 1024, generator=ge), torch.randn(1, 77, 1024, generator=ge))
     image = (np.random.RandomState(7).rand(576, 1024, 3) * 255).astype("uint8")
@@ -585,7 +593,10 @@ def run_full(args, rank, world, device):
                        "seconds_per_job": stage_mean, "frames_after_enhancement": int(n_enh),
                        "final_frames_per_job": int(n_final),
                        "parallelism": {"stage1": plan.describe(),
-                                       "enhance": ("6 (window, CFG half) units + the key-frame pre-pass's 2 over the ranks of the video's group, one all-gather per DDIM step"
+                                       "enhance": ("every window on all ranks: CFG pair x frame<->pixel sequence parallelism of degree %d inside I2VGenXLUNet (all-to-all around the "
+                                                   "temporal layers, one all-gather of the two halves' predictions per window and DDIM step); key-frame pre-pass on the CFG pair" % plan.sp.size
+                                                   if pipe.plan is not None else
+                                                   "6 (window, CFG half) units + the key-frame pre-pass's 2 over the ranks of the video's group, one all-gather per DDIM step"
                                                    if pipe.group is not None else "single GPU"),
                                        "vfi": ("frame pairs sharded over the ranks of the video's group" if pipe.group is not None else "single GPU")},
                        "precision_plan": precision_plan(),

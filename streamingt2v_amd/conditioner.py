@@ -85,7 +85,8 @@ class SVDConditioner:
         T = self.T
         img = frame[None].float()
         dev = img.device
-        cross = self.clip(self.clip_preprocess(img, always_blur=_diffusers)).float()[:, None]       # [1, 1, 1024]
+        pre = self.clip_preprocess(img, always_blur=True) if _diffusers else self.clip_preprocess(img)
+        cross = self.clip(pre).float()[:, None]                                                     # [1, 1, 1024]
         if aug_noise is not None:
             noise = aug_noise.to(dev).reshape(img.shape)
         elif _diffusers:

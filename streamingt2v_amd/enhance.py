@@ -134,14 +134,37 @@ class I2VEnhancer:
         out = ops.ddim_cfg_step(fr, pred_uncond.contiguous(), pred_text.contiguous(), self.g, a_t, a_prev, self.sched.v_prediction)
         return out.permute(1, 0, 2, 3)[None]
 
-    def denoise(self, video_latents, noise, conds, chunk_size, overlap_size, rng=random, group=None, shard="units"):
+    def _denoise_window_pair(self, window, t, cond, cfg_exchange):
+        """One window on a CFG pair of ranks (x sequence parallelism inside each half when `unet.sp` is set): this rank evaluates ITS half
+        (even rank of the pair: unconditional, odd: text), the pair all-gathers the two predictions (8.75 MB each for a 38-frame window) and
+        both apply guidance + DDIM -- every rank ends with the same window."""
+        Fr = window.shape[2]
+        both = cfg_exchange.gather(self._predict_half(window, t, cond, cfg_exchange.half).contiguous())
+        return self._combine_halves(window, t, both[:Fr], both[Fr:])
+
+    def denoise(self, video_latents, noise, conds, chunk_size, overlap_size, rng=random, group=None, shard="units", plan=None):
         """video_latents / noise fp32 [1, 4, F, h, w]; conds: one dict per window.  Returns the enhanced latents.
         group: a process group -> every DDIM step is sharded over its ranks; shard = "units" (default): the 2 x n_windows (window, CFG half)
-        units round-robin (3 windows keep 6 of 8 GPUs busy), "windows": whole windows (the round-1 form: 3 of 8)."""
+        units round-robin (3 windows keep 6 of 8 GPUs busy), "windows": whole windows (the round-1 form: 3 of 8).
+        plan (round 5): a parallel.JobPlan in "job" mode -- the SAME partition as stage 1: CFG pair x frame <-> pixel sequence parallelism of
+        degree world / 2 inside each half (I2VGenXLUNet.forward_frames with `sp`); the windows of a step run one after the other, each on ALL
+        ranks, so 8 GPUs are 8 busy GPUs whatever the number of windows (units: 6 of 8 for the shipped 3-window job)."""
         ts = self.sched.get_timesteps(self.steps, self.strength)
         self._consts = {}
         latents = self.sched.add_noise(video_latents, noise, ts[0])
         n_chunks = len(conds)
+        if plan is not None and plan.cfg_exchange is not None:
+            # a window with fewer frames than the sequence-parallel degree (the 3-frame key-frame pre-pass) runs on the CFG pair alone: the ranks of a
+            # half then compute the same prediction redundantly (identical results, no collective inside the half)
+            sp = plan.sp if (plan.sp is not None and min(chunk_size, video_latents.shape[2]) >= plan.sp.size) else None
+            prev_sp, self.unet.sp = self.unet.sp, sp
+            try:
+                for t in ts:
+                    fn = lambda idx, w, t=t: self._denoise_window_pair(w, t, conds[idx], plan.cfg_exchange)
+                    latents = blending.blend_step(latents, fn, chunk_size, overlap_size, n_chunks, rng)
+            finally:
+                self.unet.sp = prev_sp
+            return latents
         for t in ts:
             fn = lambda idx, w, t=t: self._denoise_window(w, t, conds[idx])
             if group is None:

@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from .params import Spec, check_state_dict
-from .video_model import FeedForward, _dev_bf16, _dev_f32, _spec_ln, pack_conv3x3, pack_tconv3, pack_x3, pad_rows
+from .video_model import FeedForward, _dev_bf16, _dev_f32, _gn_pooled, _spec_ln, pack_conv3x3, pack_tconv3, pack_x3, pad_rows
 
 
 def _pad32(c):
@@ -112,14 +112,27 @@ class _TemporalConv:
             self.l.append((_dev_f32(g("0.weight"), dev), _dev_f32(g("0.bias"), dev), _dev_bf16(pack_tconv3(g(f"{ci}.weight")), dev),
                            _dev_f32(g(f"{ci}.bias"), dev)))
 
-    def forward(self, x, F, Fr, H, W):
+    def forward(self, x, F, Fr, H, W, sp=None):
+        """sp (parallel.SeqParallel): x holds this rank's FRAMES of every batch element (F = B * local frames); the layer runs in the pixel
+        layout -- all Fr frames of this rank's pixel range, one all-to-all either side -- and its four norms, which pool over frames AND
+        pixels, all-reduce their sums."""
         pix = H * W
-        tv = dict(cin=self.c, T=Fr, pix=pix)
+        if sp is not None:
+            B = F // sp.frame_counts(Fr)[sp.rank]
+            x = sp.to_pixels(x, B, Fr, pix)
+            pix_l, cnt = sp.pix_local(pix), float(Fr) * pix * (self.c // 32)
+            F_t = B * Fr
+        else:
+            pix_l, F_t = pix, F
+        tv = dict(cin=self.c, T=Fr, pix=pix_l)
         h = x
         for i, (nw, nb, w, b) in enumerate(self.l):
-            h = ops.groupnorm(h, F, pix, nw, nb, 1e-5, frames_per_stat=Fr, silu=True)
+            if sp is None:
+                h = ops.groupnorm(h, F, pix, nw, nb, 1e-5, frames_per_stat=Fr, silu=True)
+            else:
+                h = _gn_pooled(h, F_t, pix_l, nw, nb, 1e-5, Fr, cnt, sp, True)
             h = ops.gemm(h, w, bias=b, temporal=tv, residual=x if i == 3 else None, out_f32=(i == 3 and ops.i2v_stream_on(self.c)))
-        return h
+        return h if sp is None else sp.to_frames(h, B, Fr, pix)
 
 
 def _spec_attn(s, p, c, inner, kv):
@@ -230,18 +243,30 @@ class _TransformerTemporal:
         self.wo2, self.bo2 = W(b + "attn2.to_out.0.weight"), Fv(b + "attn2.to_out.0.bias")
         self.ff = FeedForward(g, b + "ff.", dev)
 
-    def forward(self, x, F, Fr, H, W):
-        d, pix, M, B = self.d, H * W, F * H * W, F // Fr
+    def forward(self, x, F, Fr, H, W, sp=None):
+        """sp (parallel.SeqParallel): the frame <-> pixel split of TransformerTemporalModel (transformer_temporal.py:121-200): the whole block is
+        independent per PIXEL (attention over the frames of one pixel, row-wise norms / projections / feed-forward) except its input GroupNorm,
+        which pools over frames and pixels (all-reduce of the sums).  x arrives and leaves in the frame layout."""
+        d, pix = self.d, H * W
         st = ops.i2v_stream_on(self.c)
         e16 = ops.ELEM if x.dtype == torch.float32 else x.dtype
-        h = ops.gemm(ops.groupnorm(x, F, pix, *self.n, 1e-6, frames_per_stat=Fr), self.wpi, bias=self.bpi, out_f32=st)
+        if sp is None:
+            B, pix_l = F // Fr, pix
+            hn = ops.groupnorm(x, F, pix, *self.n, 1e-6, frames_per_stat=Fr)
+        else:
+            B, pix_l = F // sp.frame_counts(Fr)[sp.rank], sp.pix_local(pix)
+            x = sp.to_pixels(x, B, Fr, pix)
+            hn = _gn_pooled(x, B * Fr, pix_l, *self.n, 1e-6, Fr, float(Fr) * pix * (self.c // 32), sp, False)
+        M = B * Fr * pix_l
+        h = ops.gemm(hn, self.wpi, bias=self.bpi, out_f32=st)
         a = torch.empty((M, d), dtype=e16, device=x.device)
         for ln, wqkv, wo, bo in (("norm1", self.wqkv1, self.wo1, self.bo1), ("norm2", self.wqkv2, self.wo2, self.bo2)):
             qkv = ops.gemm(ops.layernorm(h, *self.ln[ln]), wqkv)
-            ops.attn_temporal(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, B, Fr, Fr, pix, self.heads)
+            ops.attn_temporal(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, B, Fr, Fr, pix_l, self.heads)
             h = ops.gemm(a, wo, bias=bo, residual=h, out_f32=st)
         h = self.ff(ops.layernorm(h, *self.ln["norm3"]), residual=h)          # consumed by proj_out only: 16 bit
-        return ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
+        out = ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
+        return out if sp is None else sp.to_frames(out, B, Fr, pix)
 
 
 class _Conv3:
@@ -469,44 +494,63 @@ class I2VGenXLUNet:
         return self
 
     # -------------------------------------------------------------------------------------------- forward
+    sp = None      # parallel.SeqParallel: forward_frames runs frame <-> pixel sequence-parallel over its group (I2VEnhancer.denoise(plan=...))
+
     def forward_frames(self, sample_frames, timestep):
-        """sample_frames fp32 [(b f), 4, H, W] (contiguous) -> noise prediction fp32 [(b f), 4, H, W]."""
+        """sample_frames fp32 [(b f), 4, H, W] (contiguous) -> noise prediction fp32 [(b f), 4, H, W].
+
+        With `self.sp` (round 5; SURVEY 8e, the frame <-> pixel split of the enhancer): every rank receives ALL frames (a 38-frame window of
+        4 x 90 x 160 latents is 8.8 MB), keeps its contiguous share of the frames of each batch element for the per-frame operators (ResnetBlock2D,
+        Transformer2DModel with its N = 14 400 spatial attention, the samplers, the head), changes to the pixel layout with one all-to-all either side
+        of every TemporalConvLayer / TransformerTemporalModel, and all-gathers the 4-channel prediction at the end: every rank returns all frames."""
         k = self._const
         B, Fr, H, W = k["B"], k["Fr"], k["H"], k["W"]
-        F = B * Fr
+        sp = self.sp
         c0 = self.cfg.block_out_channels[0]
         tt = torch.full((B,), float(timestep), dtype=torch.float32, device=self.dev)
         emb = self._embed_mlp("time_embedding.linear_1", "time_embedding.linear_2", tt, c0, rowvec=k["fps_emb"])
         emb_silu = ops.to_elem(emb, silu=True)
+        il = k["il"]
+        if sp is None:
+            Fs = Fr                                   # frames of one batch element among this rank's rows
+        else:
+            Fs = sp.frame_counts(Fr)[sp.rank]
+            assert Fs > 0, f"sequence-parallel degree {sp.size} exceeds the {Fr} frames of the window"
+            sample_frames = sp.take_frames(sample_frames, B, Fr)
+            held = k.get("il_sp")
+            if held is None or held[0] is not sp:
+                k["il_sp"] = held = (sp, sp.take_frames(il, B, Fr))
+            il = held[1]
+        F = B * Fs
 
         st0 = ops.i2v_stream_on(c0)
         if self.conv_in.w3 is not None:         # precision plan: the 8-channel stem with split-3 operands
-            x, _, _ = self.conv_in.forward(ops.nchw_to_tokens_x3(sample_frames, k["il"], None, 32), F, H, W, split3=True, out_f32=st0)
+            x, _, _ = self.conv_in.forward(ops.nchw_to_tokens_x3(sample_frames, il, None, 32), F, H, W, split3=True, out_f32=st0)
         else:
-            x, _, _ = self.conv_in.forward(ops.nchw_to_tokens(sample_frames, k["il"], None, 32), F, H, W, out_f32=st0)
-        x = self.transformer_in.forward(x, F, Fr, H, W)
+            x, _, _ = self.conv_in.forward(ops.nchw_to_tokens(sample_frames, il, None, 32), F, H, W, out_f32=st0)
+        x = self.transformer_in.forward(x, F, Fr, H, W, sp=sp)
         skips = [(x, H, W)]
         for layers, ds in self.down:
             for rn, tc, at, ta in layers:
-                x = tc.forward(rn.forward(x, emb_silu, F, Fr, H, W), F, Fr, H, W)
+                x = tc.forward(rn.forward(x, emb_silu, F, Fs, H, W), F, Fr, H, W, sp=sp)
                 if at is not None:
-                    x = ta.forward(at.forward(x, F, Fr, H, W), F, Fr, H, W)
+                    x = ta.forward(at.forward(x, F, Fs, H, W), F, Fr, H, W, sp=sp)
                 skips.append((x, H, W))
             if ds is not None:
                 x, H, W = ds.forward(x, F, H, W, out_f32=ops.i2v_stream_on(ds.cout))      # the samplers' outputs start the next level's stream
                 skips.append((x, H, W))
         r0, t0, at, ta, r1, t1 = self.mid
-        x = t0.forward(r0.forward(x, emb_silu, F, Fr, H, W), F, Fr, H, W)
-        x = ta.forward(at.forward(x, F, Fr, H, W), F, Fr, H, W)
-        x = t1.forward(r1.forward(x, emb_silu, F, Fr, H, W), F, Fr, H, W)
+        x = t0.forward(r0.forward(x, emb_silu, F, Fs, H, W), F, Fr, H, W, sp=sp)
+        x = ta.forward(at.forward(x, F, Fs, H, W), F, Fr, H, W, sp=sp)
+        x = t1.forward(r1.forward(x, emb_silu, F, Fs, H, W), F, Fr, H, W, sp=sp)
         for layers, us in self.up:
             for rn, tc, at, ta in layers:
                 s, sh, sw = skips.pop()
                 assert (sh, sw) == (H, W)
                 x = ops.concat_channels(x, s)
-                x = tc.forward(rn.forward(x, emb_silu, F, Fr, H, W), F, Fr, H, W)
+                x = tc.forward(rn.forward(x, emb_silu, F, Fs, H, W), F, Fr, H, W, sp=sp)
                 if at is not None:
-                    x = ta.forward(at.forward(x, F, Fr, H, W), F, Fr, H, W)
+                    x = ta.forward(at.forward(x, F, Fs, H, W), F, Fr, H, W, sp=sp)
             if us is not None:
                 # upsample_size = size of the next skip tensor (unet_i2vgen_xl.py:771-772): odd sizes are one short of 2x
                 _, th, tw = skips[-1]
@@ -516,6 +560,9 @@ class I2VGenXLUNet:
         else:
             x = ops.groupnorm(x, F, H * W, *self.norm_out, 1e-5, silu=True)
             x, _, _ = self.conv_out.forward(x, F, H, W, out_f32=True)
+        if sp is not None:
+            x = sp.gather_frames(x.contiguous(), B, Fr, H * W)
+            F = B * Fr
         return ops.tokens_to_nchw(x, self.cfg.out_channels, F, H, W)
 
     def forward(self, sample, timestep, fps=None, image_latents=None, image_embeddings=None, encoder_hidden_states=None, **_ignored):

@@ -310,21 +310,26 @@ class StreamingPipeline:
         if rng is None:
             rng = random.Random(c["seed"] if seed is None else seed)
         video = list(video)
+        dist_kw = dict(group=getattr(self, "group", None))
+        if getattr(self, "plan", None) is not None:
+            dist_kw["plan"] = self.plan
         images = [resize_key_image(image, getattr(codec, "w", c["enhance_width"]), getattr(codec, "h", c["enhance_height"]))]
         if use_randomized_blending:
             starts, max_idx = enhance_windows(len(video), chunk_size, overlap_size)
             key_frames = [video[s] for s in starts]                              # 1st frame of every window, enhanced first
             conds = codec.window_conditioning(images, 1, len(key_frames))         # the reference's order of random draws: image latents,
             lat = codec.encode_video(key_frames)                                 # video posterior, SDEdit noise (pipeline_i2vgen_xl.py:784-829)
-            images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng, group=getattr(self, "group", None))))   # one window: its two CFG halves on two ranks
+            images = list(codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, len(key_frames), 0, rng, **dist_kw)))   # one window: its two CFG halves on two ranks
             video = video[:max_idx]
         else:
             starts, chunk_size, overlap_size = [0], len(video), 0
         conds = codec.window_conditioning(images, len(starts), chunk_size)
         lat = codec.encode_video(video)
-        # self.group (a torch.distributed group, default None): the blending windows of every DDIM step are sharded over its ranks
-        # (blending.blend_step_sharded: identical offsets on every rank, one all-gather of the window outputs per step)
-        return codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng, group=getattr(self, "group", None)))
+        # self.group (a torch.distributed group, default None): the (window, CFG half) units of every DDIM step are sharded over its ranks
+        # (blending.blend_step_units_sharded: identical offsets on every rank, one all-gather of the predictions per step);
+        # self.plan (a parallel.JobPlan in "job" mode, default None; takes precedence): CFG pair x frame <-> pixel sequence parallelism inside every
+        # window's UNet evaluation -- all ranks busy whatever the number of windows (I2VEnhancer.denoise)
+        return codec.decode(enh.denoise(lat, codec.noise_like(lat), conds, chunk_size, overlap_size, rng, **dist_kw))
 
     def interpolate_video(self, video, dest_num_frames, **kwargs):
         """inference_i2v.py:211-224.  vfi: an `ema_vfi.EMAVFI` (the native EMA-VFI) or any callable vfi(video, dest_num_frames)."""

@@ -543,7 +543,7 @@ class _Conv:
             ho, wo = 2 * H, 2 * W
         else:
             ho, wo = H, W
-        assert not split3 or (self.w3 is not None and x.shape[1] == 3 * self.cin_pad and x.dtype != torch.float32), \
+        assert not split3 or (self.w3 is not None and x.shape[1] == 3 * self.cin_pad), \
             "split-3 rows handed to a convolution prepared without the rim weights (ops.EXACT_RIM at load time) or of the wrong width"
         if self.w3 is not None and (split3 or x.dtype == torch.float32):
             if not split3:
@@ -692,8 +692,9 @@ class _EncoderBase:
             elif isinstance(m, SpatialVideoTransformer):
                 h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp)
             else:
-                # stem / Downsample / Upsample convolutions write the stream; a rim stem (w3) is fed the split-3 rows of input_tokens()
-                h, H, W = m.forward(h, F, H, W, split3=m.w3 is not None and h.dtype != torch.float32, out_f32=ops.stream_on(m.cout))
+                # stem / Downsample / Upsample convolutions write the stream; the only rim convolution here is the stem (x3=True), and a rim stem
+                # (w3) is always fed the split-3 rows input_tokens() makes for it
+                h, H, W = m.forward(h, F, H, W, split3=m.w3 is not None, out_f32=ops.stream_on(m.cout))
         return h, H, W
 
     def _local_conditioning(self, timesteps, context, y, T, sp):

@@ -348,9 +348,21 @@ def i2v_image_temporal_encoder(x, params, batch, frames, h, w):
     return xo.permute(0, 2, 3, 1).reshape(batch * frames, 4, h, w).contiguous()
 
 
+def ddim_cfg_step(x, pred_uncond, pred_cond, guidance_scale, alpha_t, alpha_prev, v_prediction=True, out=None):
+    """csrc/i2v.hip ddim_cfg_step_kernel: guidance, then diffusers DDIMScheduler.step with eta 0 (pipeline_i2vgen_xl.py:872-885)."""
+    v = pred_uncond if pred_cond is None else pred_uncond + guidance_scale * (pred_cond - pred_uncond)
+    sa, sb, spa, spb = alpha_t ** 0.5, (1.0 - alpha_t) ** 0.5, alpha_prev ** 0.5, (1.0 - alpha_prev) ** 0.5
+    x0, eps = (sa * x - sb * v, sa * v + sb * x) if v_prediction else ((x - sb * v) / sa, v)
+    res = spa * x0 + spb * eps
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
          "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3",
-         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder", "ff_geglu_fused")
+         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder", "ff_geglu_fused", "ddim_cfg_step")
 
 
 def install(monkeypatch=None):

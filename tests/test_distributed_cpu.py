@@ -299,3 +299,84 @@ def test_preflight_times_out_on_a_hung_backend_and_falls_back_to_replicas():
         assert why is not None and "preflight failed" in why and use_ctl, (rank, why)
         assert slowest == 2.0 and dt < 60.0, (rank, slowest, dt)
     assert any("timed out" in r[2] for r in res)
+
+
+# ---- enhancement stage, round 5: frame <-> pixel sequence parallelism inside I2VGenXLUNet, and the CFG-pair x SP plan of I2VEnhancer.denoise -------
+
+def _enh_sp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(2)
+    from tests import svd_shim
+    svd_shim.install()
+    from oracle import cases
+    from streamingt2v_amd import parallel
+    from streamingt2v_amd.enhance import DDIMSchedule, I2VEnhancer
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from streamingt2v_amd.params import init_by_name
+    assert parallel.init_from_env(backend="gloo") == world
+    try:
+        torch.set_grad_enabled(False)
+        kw, ti = cases.tiny_i2v_kwargs(), cases.TINY_I2V
+        unet = I2VGenXLUNet(I2VConfig(block_out_channels=kw["block_out_channels"], layers_per_block=kw["layers_per_block"],
+                                      cross_attention_dim=kw["cross_attention_dim"], attn_levels=(True, True, False)))
+        unet.load_state_dict(init_by_name(unet.spec(), seed=5), device="cpu")
+        inp = cases.tiny_i2v_inputs()
+        call = lambda: unet(inp["sample"], inp["t"], fps=inp["fps"], image_latents=inp["image_latents"], image_embeddings=inp["image_embeddings"],
+                            encoder_hidden_states=inp["text"])[0]
+        ref = call()                                                       # CFG batch 2 x 6 frames @ 9 x 16: single process
+        # (1) the UNet alone, sequence parallel over groups of 2 ranks (4 ranks: two independent groups); uneven frames with degree 4 (6 = 2 2 1 1)
+        groups = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
+        unet.sp = parallel.SeqParallel(groups[rank // 2])
+        e_sp2 = (call() - ref).abs().max().item()
+        e_sp4 = 0.0
+        if world == 4:
+            unet.sp = parallel.SeqParallel(dist.group.WORLD)
+            e_sp4 = (call() - ref).abs().max().item()
+        unet.sp = None
+        # (2) the denoising loop with randomized blending on the stage-1 job plan (CFG pair x SP of degree world / 2) against the single-process loop:
+        #     2 overlapping windows of 6 frames, 3 DDIM steps; then a 1-window "key-frame pre-pass" of 1 frame (fewer frames than ranks: the pair alone)
+        chunk, overlap, H, W, cd = ti["F"], 2, ti["h"], ti["w"], ti["cross_attention_dim"]
+        n_frames = 2 * chunk - overlap
+        g = torch.Generator(); g.manual_seed(2024)
+        video, noise = torch.randn(1, 4, n_frames, H, W, generator=g) * 0.5, torch.randn(1, 4, n_frames, H, W, generator=g)
+        conds = []
+        for i in range(2):
+            il = torch.randn(1, 4, chunk, H, W, generator=g) * 0.7
+            emb, text = torch.randn(1, cd, generator=g), torch.randn(1, ti["text_tokens"], cd, generator=g)
+            conds.append(dict(fps=torch.tensor([8, 8]), image_latents=torch.cat([il, il]), image_embeddings=torch.cat([torch.zeros_like(emb), emb]),
+                              text=torch.cat([torch.zeros_like(text), text])))
+        enh = I2VEnhancer(unet, DDIMSchedule(), guidance_scale=9.0, num_inference_steps=10, strength=0.35)
+        one = enh.denoise(video, noise, conds, chunk, overlap, rng=random.Random(33))
+        plan = parallel.JobPlan(world, rank, "job", frames_cond=chunk, min_pix=12)
+        two = enh.denoise(video, noise, conds, chunk, overlap, rng=random.Random(33), plan=plan)
+        e_loop = ((two - one).abs().max() / one.abs().max()).item()
+        c1 = [dict(conds[0], image_latents=conds[0]["image_latents"][:, :, :1])]
+        k_one = enh.denoise(video[:, :, :1], noise[:, :, :1], c1, 1, 0, rng=random.Random(33))
+        k_two = enh.denoise(video[:, :, :1], noise[:, :, :1], c1, 1, 0, rng=random.Random(33), plan=plan)
+        e_key = ((k_two - k_one).abs().max() / k_one.abs().max()).item()
+        out.put((rank, e_sp2, e_sp4, e_loop, e_key, plan.mode, unet.sp is None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_enhancer_sequence_parallel_equals_single_process(world):
+    """The frame <-> pixel split of the enhancer (TransformerTemporalModel / TemporalConvLayer in the pixel layout with all-reduced GroupNorm sums,
+    everything else on the rank's frames, all-gather of the prediction) reproduces I2VGenXLUNet.forward on every rank; I2VEnhancer.denoise on the
+    stage-1 job plan (CFG pair x sequence parallelism) reproduces the single-process loop with randomized blending, pre-pass included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_enh_sp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, e_sp2, e_sp4, e_loop, e_key, mode, sp_restored in res:
+        assert e_sp2 < 2e-4 and e_sp4 < 2e-4, (rank, e_sp2, e_sp4)          # fp32 on both sides: summation order of the pooled norms only
+        assert e_loop < 5e-4 and e_key < 5e-4, (rank, e_loop, e_key)
+        assert mode == "job" and sp_restored

@@ -187,8 +187,13 @@ def _enh_worker(rank, world, port, out):
         one = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33))
         units = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33), group=dist.group.WORLD)
         wins = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33), group=dist.group.WORLD, shard="windows")
+        # round 5: the stage-1 job plan on the enhancer -- CFG pair x frame <-> pixel sequence parallelism of degree world / 2 inside I2VGenXLUNet
+        # (world 2: the pair alone = bit-identical; world 4: pooled GroupNorm sums are added in another order -> a few 16-bit roundings flip)
+        plan = parallel.JobPlan(world, rank, "job", frames_cond=chunk, min_pix=12)
+        planned = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33), plan=plan)
         torch.cuda.synchronize()
-        out.put(dict(rank=rank, units_identical=bool(torch.equal(one, units)), windows_identical=bool(torch.equal(one, wins)), e_units=_rel(units, one)))
+        out.put(dict(rank=rank, units_identical=bool(torch.equal(one, units)), windows_identical=bool(torch.equal(one, wins)), e_units=_rel(units, one),
+                     plan_mode=plan.mode, plan_sp=plan.sp.size if plan.sp is not None else 1, e_plan=_rel(planned, one), plan_identical=bool(torch.equal(one, planned))))
     finally:
         dist.destroy_process_group()
 
@@ -214,3 +219,7 @@ def test_enhancer_cfg_half_units_on_hip_kernels_multi_process(world):
               f"(relative L2 {d['e_units']:.2e}), whole windows bit-identical {d['windows_identical']}")
         assert d["windows_identical"], d
         assert d["units_identical"], d
+        print(f"[enhancer on the job plan, world {world}, rank {d['rank']}] CFG pair x sequence parallelism of degree {d['plan_sp']}: relative L2 vs single process "
+              f"{d['e_plan']:.2e}, bit-identical {d['plan_identical']}")
+        assert d["plan_mode"] == "job" and d["plan_sp"] == world // 2
+        assert d["plan_identical"] if world == 2 else d["e_plan"] < 4e-3, d

@@ -73,8 +73,8 @@ for step in "$@"; do
               python tools/rocprof_summary.py $DB $O/enhance_kernel_stats.txt > /dev/null 2>>$O/rt_enh_err.log
               rm -rf $O/prof_enh; head -12 $O/enhance_roofline_table.txt | cut -c1-200 ;;
     full)     timeout 900 python bench.py --workload full --steps 1 --warmup 0 > $O/bench_full_pipeline.json 2>$O/bench_full.err; cut -c1-400 $O/bench_full_pipeline.json ;;
-    suite)    timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/gpu_tests_full.log 2>&1
-              grep -E "^\[|passed|failed|FAILED" $O/gpu_tests_full.log | grep -v "Gloo\|W924\|c10d" > $O/gpu_test_lines.txt; tail -1 $O/gpu_test_lines.txt
+    suite)    timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=40 > $O/gpu_tests_full.log 2>&1
+              grep -E "^\[|passed|failed|FAILED" $O/gpu_tests_full.log | grep -v "Gloo\|W924\|c10d" > $O/gpu_test_lines.txt; tail -1 $O/gpu_test_lines.txt; grep -A42 "slowest 40 durations" $O/gpu_tests_full.log > $O/gpu_test_durations.txt; head -14 $O/gpu_test_durations.txt
               (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -i "smoke") > $O/smoke.txt; cat $O/smoke.txt ;;
     pmc)      bash tools/pmc_round4.sh $O ;;
     *)        echo "unknown step $step" ;;
