@@ -19,8 +19,26 @@
 //     sets swap roles), then the 20 MFMAs of O^T for chunk c.
 // Work per 128-row tile and wave: 40 chunks x 60 MFMA 32x32x16 = 76.8 k matrix-pipe cycles; HBM traffic: X read once, R read once, Y written once.
 #include "svd_common.h"
+#include <stdlib.h>
 
 namespace {
+
+#ifdef SVD_FF_PROBES
+__device__ int ff_dephase_probe = -1;          // probe builds: >= 0 overrides FF_DEPHASE_SLEEPS (units of s_sleep 127 per start slot)
+#endif
+constexpr int FF_DEPHASE_SLEEPS = 0;             // start de-phasing of the workgroups (see ff_start_delay); 0 = off: MEASURED, no gain (profiles/r05_ff_fused_probe_dephase.txt:
+                                                 // 1.382 ms -> 1.351 / 1.391 / 1.435 ms with slots of 4 / 8 / 12 us at M = 460 800; slower at every setting at M = 129 024)
+
+// All workgroups walk the same number of equal tiles: without help every CU runs its tile prologue / epilogue (X, R in, Y out) at the same moment and
+// its MFMA phases at the same moment -- HBM idles, then saturates.  Workgroup b starts (b mod 16) slots late; a slot is `sleeps` x s_sleep 127 (~4 us).
+__device__ __forceinline__ void ff_start_delay() {
+    int n = FF_DEPHASE_SLEEPS;
+#ifdef SVD_FF_PROBES
+    if (ff_dephase_probe >= 0) n = ff_dephase_probe;
+#endif
+    const int k = (blockIdx.x & 15) * n;
+    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+}
 
 constexpr int FF_C = 320;                        // channels of the level: K of GEMM 1, N of GEMM 2
 constexpr int FF_NS = FF_C / 16;                 // 20 k-steps of GEMM 1
@@ -43,6 +61,7 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
                                                                 const void* __restrict__ S, int64_t lds, float alpha,
                                                                 void* __restrict__ Y, int64_t ldy, int M, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    ff_start_delay();
     const uint32_t sbase = lds_addr_of(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -282,6 +301,252 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
     svd_wait_dma();          // the ring's last requests (chunks of a tile that does not exist) must not outlive the workgroup's LDS
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// Second form (round 5): the same computation on EIGHT waves per workgroup, two per SIMD -- built on the hypothesis that the four-wave kernel above is
+// bound by ONE wave's issue stream (~535 instructions per 60 MFMAs against the ~5 fillers per 32-cycle MFMA gap that MI355X_MICROARCH.md measures as free
+// for one wave per SIMD).  MEASURED: bit-identical and NOT faster (1.39 vs 1.38 ms at M = 460 800) -- the hypothesis is wrong.  What the probe variants of
+// both forms say instead (profiles/r05_ff_fused_probe_8waves.txt): the matrix pipe alone would need 0.56 ms (registers-only MFMA loop: 2.0-2.07 PFLOP/s at
+// the clock the chip holds); with DMA, GELU, barrier AND fragment reads stripped the eight-wave kernel still takes 0.83 ms -- the remainder is the tile
+// prologue / epilogue (X, R in, Y out: 1.47 GB that every CU moves at the same time, because all workgroups walk their 14-15 tiles in lock step) -- and the
+// four removed pieces cost 0.16 (LDS-DMA) / 0.09 (GELU) / 0.11 (barrier) / 0.20 ms (fragment reads: 240 KiB of ds_read_b128 per chunk and CU, as much LDS
+// time as the chunk's MFMAs take on the matrix pipe) when removed one at a time.  Deeper fragment prefetch (7 ahead) changes nothing.  The kernel stays in
+// the library as an A/B form (SVD_FF_WAVES=8).  Here a PAIR of waves shares 32 token rows: both hold the rows' X fragments; wave q of the pair computes
+// S^T of hidden tile q of every chunk (20 MFMAs), gates it, and hands its packed 16-unit GEGLU fragment to the partner through a 1-KiB LDS slot
+// (written before the step's workgroup barrier, read after it); each wave then accumulates ITS half of the output channels (5 tiles of 32) over both
+// hidden tiles (10 MFMAs).  Per wave and chunk: 30 MFMAs, 30 fragment reads, 4 GELU pairs, 9 DMA pieces -- half of the four-wave kernel's stream --
+// and a SIMD always has a second wave to issue from.  Same packed weight image, same arithmetic per element in the same order (GEMM 2 adds hidden
+// tile 0 before tile 1 in both forms), so the results are bit-identical to the four-wave kernel.
+constexpr int F8_LDS_X = FF_LDS_TOTAL;                         // exchange: 2 (step parity) x 8 (wave) x 1 KiB
+constexpr int F8_LDS_TOTAL = F8_LDS_X + 2 * 8 * 1024;          // 142 592 B
+constexpr int F8_NO = FF_NO / 2;                               // 5 output tiles (160 channels) per wave
+
+// PV (probe builds only; results are WRONG for PV != 0; bit mask): 1 = no LDS-DMA in the steps, 2 = no GELU arithmetic, 4 = no workgroup barrier in the steps,
+// 8 = no fragment reads in the steps (stale registers), 16 = fragments 7 MFMAs ahead (ring of 8) instead of 3
+template <class E, int RES, bool OUT32, bool BLEND = false, int PV = 0>
+__global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp, int nch,
+                                                                 const float* __restrict__ b2, const void* __restrict__ R, int64_t ldr,
+                                                                 const void* __restrict__ S, int64_t lds, float alpha,
+                                                                 void* __restrict__ Y, int64_t ldy, int M, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t sbase = lds_addr_of(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave >> 1, q = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const uint32_t voff = (uint32_t)lane * 16u;
+
+    auto glds = [&](const char* src, uint32_t dst) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(dst) : "m0");
+    };
+    // piece k of this wave's 6 W1 pieces (wave + 8 k, clamped to the last piece: the clamped copies write the same bytes to the same place) / 3 W2 pieces
+    auto dma_w1_piece = [&](const char* src, uint32_t dst, int k) __attribute__((always_inline)) {
+        int p = wave + 8 * k;
+        p = p > FF_W1_PIECES - 1 ? FF_W1_PIECES - 1 : p;
+        glds(src + p * 1024, dst + p * 1024);
+    };
+    auto dma_w2_piece = [&](const char* src, uint32_t dst, int k) __attribute__((always_inline)) {
+        int p = wave + 8 * k;
+        p = p > FF_W2_PIECES - 1 ? FF_W2_PIECES - 1 : p;
+        glds(src + p * 1024, dst + p * 1024);
+    };
+
+    uint4 xf[FF_NS];
+    auto load_x = [&](int tile) {
+        int row = tile * 128 + pair * 32 + l31;
+        row = row < M ? row : M - 1;
+        const svd_bf16* xp = X + (int64_t)row * ldx + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < FF_NS; ++s) xf[s] = *(const uint4*)(xp + 16 * s);
+    };
+    // S^T of THIS wave's tile (q) starts from its 32 biases: rows 8 j + 4 hi + e of the tile <-> registers 4 j + e
+    auto bias_init = [&](const char* w, f32x16_t& s_acc) __attribute__((always_inline)) {
+        const char* bp = w + 2 * FF_NS * 1024 + q * 128 + hi * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 b = *(const float4*)(bp + j * 32);
+            s_acc[4 * j + 0] = b.x; s_acc[4 * j + 1] = b.y; s_acc[4 * j + 2] = b.z; s_acc[4 * j + 3] = b.w;
+        }
+    };
+    auto gemm1_plain = [&](int slot, f32x16_t& s_acc) __attribute__((always_inline)) {
+        const char* w = smem + slot * FF_W1_BYTES;
+        bias_init(w, s_acc);
+        const char* wl = w + q * 1024 + lane * 16;             // fragment (k-step s, tile q) is piece 2 s + q
+        uint4 fr[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fr[i] = *(const uint4*)(wl + i * 2048);
+#pragma unroll
+        for (int i = 0; i < FF_NS; ++i) {
+            if (i + 3 < FF_NS) fr[(i + 3) & 3] = *(const uint4*)(wl + (i + 3) * 2048);
+            s_acc = E::mfma(fr[i & 3], xf[i], s_acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    f32x16_t o_acc[F8_NO];
+
+    for (int i = tid; i < FF_C; i += 512) ((float*)(smem + FF_LDS_B2))[i] = b2[i];
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dma_w1_piece(Wp, sbase, k);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dma_w1_piece(Wp + (int64_t)(1 % nch) * FF_BLOB, sbase + FF_W1_BYTES, k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dma_w2_piece(Wp + FF_W1_BYTES, sbase + FF_LDS_W2, k);
+        load_x(tile);
+    }
+    svd_wait_dma();
+    __syncthreads();
+
+    f32x16_t s_a, s_b;
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int o = 0; o < F8_NO; ++o)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o_acc[o][i] = 0.f;
+        gemm1_plain(0, s_a);                 // S^T tile q of chunk 0 (W1 slot 0: nch is even, every tile starts on slot parity 0)
+        __syncthreads();                     // every wave is done with W1 slot 0 before step 0 overwrites it with chunk 2
+        // One chunk.  `sc` holds S^T (tile q) of chunk c, `sn` receives that of chunk c + 1 from W1 slot PAR ^ 1.
+        //   phase A, 20 slots: MFMA i of S^T(c + 1) | the fragment read for MFMA i + 3 | one fifth of a GELU pair of chunk c (4 pairs x 5 stages) |
+        //                      the wave's 6 W1 pieces of chunk c + 2 (into the slot chunk c was read from one step ago) at slots 1, 4, 7, 10, 13, 16
+        //   hand-over: the packed GEGLU fragment -> LDS, wait for the DMA, workgroup barrier, the partner's fragment <- LDS
+        //   phase B, 10 slots: MFMA of O^T(c) (hidden tile 0, then tile 1: one of them is the partner's) | the W2 fragment read 3 ahead | the wave's 3 W2 pieces of
+        //                      chunk c + 1 at slots 1, 4, 7 (only now: the slot they overwrite was read in phase B of the step before, which every
+        //                      wave has left once it passed this step's barrier) | (LOADX) two row loads of the next tile per slot
+        auto step = [&]<int PAR, bool LAST, bool LOADX>(int c, f32x16_t& sc, f32x16_t& sn) __attribute__((always_inline)) {
+            int c2 = c + 2; c2 = c2 >= nch ? c2 - nch : c2;
+            int c1 = c + 1; c1 = c1 >= nch ? 0 : c1;
+            const char* src1 = Wp + (int64_t)c2 * FF_BLOB;
+            const char* src2 = Wp + (int64_t)c1 * FF_BLOB + FF_W1_BYTES;
+            const uint32_t dst1 = sbase + PAR * FF_W1_BYTES, dst2 = sbase + FF_LDS_W2 + (PAR ^ 1) * FF_W2_BYTES;
+            const char* w1 = smem + (PAR ^ 1) * FF_W1_BYTES;
+            const char* w1l = w1 + q * 1024 + lane * 16;
+            constexpr int RD = (PV & 16) ? 8 : 4;            // fragment ring: RD - 1 MFMAs ahead
+            uint4 fr[RD];
+            if constexpr (!LAST) {
+                bias_init(w1, sn);
+#pragma unroll
+                for (int i = 0; i < RD - 1; ++i) fr[i] = *(const uint4*)(w1l + i * 2048);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t hp[4];
+            svd_f32x2 gt, gmx, gr, gq;
+            const svd_f32x2 k6 = {1.775515804e-05f, 1.775515804e-05f}, k5 = {-6.477575890e-04f, -6.477575890e-04f}, k4 = {7.724042874e-03f, 7.724042874e-03f},
+                            k3 = {-5.292673725e-02f, -5.292673725e-02f}, k2 = {-4.590827371e-01f, -4.590827371e-01f}, k1 = {-1.151116856e+00f, -1.151116856e+00f},
+                            km1 = {-1.0f, -1.0f};
+#pragma unroll
+            for (int i = 0; i < FF_NS; ++i) {
+                if constexpr (!LAST && !(PV & 8)) {
+                    if (i + RD - 1 < FF_NS) fr[(i + RD - 1) & (RD - 1)] = *(const uint4*)(w1l + (i + RD - 1) * 2048);
+                }
+                if constexpr (PV & 2) { if (i % 5 == 4) hp[i / 5] = __builtin_bit_cast(uint32_t, sc[2 * (i / 5)]); } else
+                {   // GELU pair pr = i / 5 (registers 2 pr, 2 pr + 1: value; 8 + 2 pr, 9 + 2 pr: gate), stage i % 5: gelu_erf_f2 (svd_common.h), bit for bit
+                    const int pr = i / 5, st = i % 5, e = 2 * pr;
+                    if (st == 0) {
+                        asm("v_min_f32 %0, %2, |%1|" : "=v"(gt[0]) : "v"(sc[8 + e]), "s"(7.0f));
+                        asm("v_min_f32 %0, %2, |%1|" : "=v"(gt[1]) : "v"(sc[9 + e]), "s"(7.0f));
+                        asm("v_max_f32 %0, 0, %1" : "=v"(gmx[0]) : "v"(sc[8 + e]));
+                        asm("v_max_f32 %0, 0, %1" : "=v"(gmx[1]) : "v"(sc[9 + e]));
+                        gr = __builtin_elementwise_fma(k6, gt, k5);
+                    } else if (st == 1) {
+                        gr = __builtin_elementwise_fma(gr, gt, k4);
+                        gr = __builtin_elementwise_fma(gr, gt, k3);
+                    } else if (st == 2) {
+                        gr = __builtin_elementwise_fma(gr, gt, k2);
+                        gr = __builtin_elementwise_fma(gr, gt, k1);
+                    } else if (st == 3) {
+                        const svd_f32x2 ex = __builtin_elementwise_fma(gr, gt, km1);
+                        gq[0] = __builtin_amdgcn_exp2f(ex[0]); gq[1] = __builtin_amdgcn_exp2f(ex[1]);
+                    } else {
+                        svd_f32x2 ax;
+                        ax[0] = __builtin_fabsf(sc[8 + e]); ax[1] = __builtin_fabsf(sc[9 + e]);
+                        const svd_f32x2 gl = __builtin_elementwise_fma(-ax, gq, gmx);
+                        hp[pr] = E::pack(sc[e] * gl[0], sc[e + 1] * gl[1]);
+                    }
+                }
+                if constexpr (!(PV & 1)) { if (i % 3 == 1 && i / 3 < 6) dma_w1_piece(src1, dst1, i / 3); }
+                if constexpr (!LAST) sn = E::mfma(fr[i & (RD - 1)], xf[i], sn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- hand-over of the GEGLU fragments inside the pair, and the step's barrier
+            uint4 own;
+            own.x = hp[0]; own.y = hp[1]; own.z = hp[2]; own.w = hp[3];
+            *(uint4*)(smem + F8_LDS_X + ((PAR * 8 + wave) << 10) + lane * 16) = own;
+            svd_wait_dma();
+            if constexpr (!(PV & 4)) __syncthreads();
+            const uint4 other = *(const uint4*)(smem + F8_LDS_X + ((PAR * 8 + (wave ^ 1)) << 10) + lane * 16);
+            // ---- O^T(c): fragment (tile t, output tile o) is piece t * 10 + o of the W2 slot; this wave: o = 5 q .. 5 q + 4, t = 0 then t = 1
+            const uint4 h0 = q == 0 ? own : other, h1 = q == 0 ? other : own;
+            const char* w2l = smem + FF_LDS_W2 + PAR * FF_W2_BYTES + (5 * q) * 1024 + lane * 16;
+            auto w2_piece = [&](int j) __attribute__((always_inline)) { return w2l + ((j / F8_NO) * FF_NO + (j % F8_NO)) * 1024; };
+            int xrow = 0;
+            if constexpr (LOADX) {
+                const int nt = tile + (int)gridDim.x;
+                xrow = (nt < ntiles ? nt : tile) * 128 + pair * 32 + l31;
+                xrow = xrow < M ? xrow : M - 1;
+            }
+            const svd_bf16* xp = X + (int64_t)xrow * ldx + 8 * hi;
+            uint4 f2[RD];
+#pragma unroll
+            for (int j = 0; j < RD - 1; ++j) f2[j] = *(const uint4*)w2_piece(j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2 * F8_NO; ++j) {
+                if constexpr (!(PV & 8)) { if (j + RD - 1 < 2 * F8_NO) f2[(j + RD - 1) & (RD - 1)] = *(const uint4*)w2_piece(j + RD - 1); }
+                if constexpr (!(PV & 1)) { if (j % 3 == 1 && j / 3 < 3) dma_w2_piece(src2, dst2, j / 3); }
+                if constexpr (LOADX) { xf[2 * j] = *(const uint4*)(xp + 16 * (2 * j)); xf[2 * j + 1] = *(const uint4*)(xp + 16 * (2 * j + 1)); }
+                o_acc[j % F8_NO] = E::mfma(f2[j & (RD - 1)], j < F8_NO ? h0 : h1, o_acc[j % F8_NO]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int c = 0; c + 2 < nch; c += 2) {
+            step.template operator()<0, false, false>(c, s_a, s_b);
+            step.template operator()<1, false, false>(c + 1, s_b, s_a);
+        }
+        step.template operator()<0, false, true>(nch - 2, s_a, s_b);
+        step.template operator()<1, true, false>(nch - 1, s_b, s_a);
+        // ---- epilogue: lane holds row l31 of the pair's 32, channels 160 q + 32 o + 8 j + 4 hi .. + 3 in o_acc[o][4 j .. 4 j + 3]
+        const int row = (tile * 128 + pair * 32 + l31);
+        if (row < M) {
+            const int cb = 160 * q + 4 * hi;
+            const float* bl = (const float*)(smem + FF_LDS_B2) + cb;
+#pragma unroll
+            for (int o = 0; o < F8_NO; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = 32 * o + 8 * j;
+                    const float4 b = *(const float4*)(bl + ch);
+                    float4 v = {o_acc[o][4 * j] + b.x, o_acc[o][4 * j + 1] + b.y, o_acc[o][4 * j + 2] + b.z, o_acc[o][4 * j + 3] + b.w};
+                    if constexpr (RES == 2) {
+                        const float4 r = *(const float4*)((const float*)R + (int64_t)row * ldr + cb + ch);
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    } else if constexpr (RES == 1) {
+                        const uint2 r = *(const uint2*)((const svd_bf16*)R + (int64_t)row * ldr + cb + ch);
+                        v.x += E::lo(r.x); v.y += E::hi(r.x); v.z += E::lo(r.y); v.w += E::hi(r.y);
+                    }
+                    if constexpr (BLEND) {
+                        const float beta = 1.0f - alpha;
+                        float4 sv;
+                        if constexpr (RES == 2) {
+                            sv = *(const float4*)((const float*)S + (int64_t)row * lds + cb + ch);
+                        } else {
+                            const uint2 r = *(const uint2*)((const svd_bf16*)S + (int64_t)row * lds + cb + ch);
+                            sv.x = E::lo(r.x); sv.y = E::hi(r.x); sv.z = E::lo(r.y); sv.w = E::hi(r.y);
+                        }
+                        v.x = alpha * sv.x + beta * v.x; v.y = alpha * sv.y + beta * v.y; v.z = alpha * sv.z + beta * v.z; v.w = alpha * sv.w + beta * v.w;
+                    }
+                    if constexpr (OUT32) {
+                        *(float4*)((float*)Y + (int64_t)row * ldy + cb + ch) = v;
+                    } else {
+                        uint2 u; u.x = E::pack(v.x, v.y); u.y = E::pack(v.z, v.w);
+                        *(uint2*)((svd_bf16*)Y + (int64_t)row * ldy + cb + ch) = u;
+                    }
+                }
+        }
+    }
+    svd_wait_dma();
+}
+
 }  // namespace
 
 // X [M, 320] 16-bit rows (the LayerNorm output), Wp: packed image (svd_ff_fused_pack_bytes(hidden) bytes, layout above / ops.pack_ff_fused),
@@ -289,7 +554,10 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
 extern "C" int64_t svd_ff_fused_pack_bytes(int32_t hidden) { return hidden > 0 && hidden % 64 == 0 ? (int64_t)(hidden / 32) * FF_BLOB : (int64_t)SVD_EINVAL; }
 
 #ifdef SVD_FF_PROBES
-extern "C" { int svd_ff_probe_variant = 0; }
+extern "C" { int svd_ff_probe_variant = 0; }      // 1..4 / 101..116: timing probes of the four- / eight-wave kernel; -1: the four-wave kernel; 0: the eight-wave kernel
+#define FF_FORCE4 && svd_ff_probe_variant == -1
+#else
+#define FF_FORCE4
 #endif
 extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t channels, int32_t hidden, const float* b2, const void* R,
                                   int64_t ldr, const void* S, int64_t lds, float alpha, int32_t res_f32, void* Y, int64_t ldy, int32_t out_f32, int64_t M,
@@ -310,29 +578,55 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
     }
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     const int nch = hidden / 32;
+    // SVD_FF_WAVES=8 (A/B switch): the eight-wave form (wave pairs, two per SIMD) instead of the four-wave one.  Bit-identical results, and the same
+    // time to the per cent (profiles/r05_ff_fused_probe_8waves.txt: 1.39 vs 1.38 ms at M = 460 800, stage-1 line 2.2823 vs 2.2824 frames/s): the default
+    // stays the form every parity number of the round was measured on.
+    static const bool four_waves = [] { const char* e = getenv("SVD_FF_WAVES"); return !(e && e[0] == '8'); }();
 #define FF_LAUNCH(RES, OUT)  FF_LAUNCH2(RES, OUT, false)
 #define FF_LAUNCH2(RES, OUT, BL)                                                                                                            \
     do {                                                                                                                                 \
         SVD_DISPATCH_DTYPE(dtype, {                                                                                                      \
-            auto kern = ff_geglu_fused_kernel<E, RES, OUT, BL>;                                                                           \
-            static bool attr_set = false;                                                                                                \
-            if (!attr_set) {                                                                                                             \
-                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
-                attr_set = true;                                                                                                         \
+            if (four_waves FF_FORCE4) {          /* probe builds: the variant alone decides */                                                                                                  \
+                auto kern = ff_geglu_fused_kernel<E, RES, OUT, BL>;                                                                       \
+                static bool attr_set = false;                                                                                            \
+                if (!attr_set) {                                                                                                         \
+                    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
+                    attr_set = true;                                                                                                     \
+                }                                                                                                                        \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
+                                   alpha, Y, ldy, (int)M, ntiles);                                                                                      \
+            } else {                                                                                                                     \
+                auto kern = ff_geglu_fused8_kernel<E, RES, OUT, BL>;                                                                      \
+                static bool attr_set = false;                                                                                            \
+                if (!attr_set) {                                                                                                         \
+                    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
+                    attr_set = true;                                                                                                     \
+                }                                                                                                                        \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
+                                   alpha, Y, ldy, (int)M, ntiles);                                                                                      \
             }                                                                                                                            \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
-                               alpha, Y, ldy, (int)M, ntiles);                                                                                          \
         });                                                                                                                              \
     } while (0)
 #ifdef SVD_FF_PROBES
-    if (svd_ff_probe_variant) {
+    if (svd_ff_probe_variant > 0) {
 #define FF_PROBE(PVV)                                                                                                                    \
         do {                                                                                                                             \
             auto kern = ff_geglu_fused_kernel<ElemF16, 2, true, false, PVV>;                                                                   \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles); \
         } while (0)
-        switch (svd_ff_probe_variant) { case 1: FF_PROBE(1); break; case 2: FF_PROBE(2); break; case 3: FF_PROBE(3); break; default: FF_PROBE(4); break; }
+#define FF_PROBE8(PVV)                                                                                                                   \
+        do {                                                                                                                             \
+            auto kern = ff_geglu_fused8_kernel<ElemF16, 2, true, false, PVV>;                                                              \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles); \
+        } while (0)
+        switch (svd_ff_probe_variant) {
+            case 1: FF_PROBE(1); break; case 2: FF_PROBE(2); break; case 3: FF_PROBE(3); break; case 4: FF_PROBE(4); break;
+            case 101: FF_PROBE8(1); break; case 102: FF_PROBE8(2); break; case 104: FF_PROBE8(4); break; case 108: FF_PROBE8(8); break;
+            case 116: FF_PROBE8(16); break; case 115: FF_PROBE8(15); break; case 107: FF_PROBE8(7); break; case 103: FF_PROBE8(3); break;
+            default: return SVD_EINVAL;
+        }
         SVD_CHECK_LAUNCH("ff_geglu_fused(probe)");
         return SVD_OK;
     }

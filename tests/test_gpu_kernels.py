@@ -416,7 +416,7 @@ def test_x3_convolution_matches_fp32(ops, cin, cout, stride, H, W):
         ref = F.conv2d(x.double(), sd["c.weight"].double().cuda(), sd["c.bias"].double().cuda(), stride=stride, padding=1).float()
         refm = ref.permute(0, 2, 3, 1).reshape(-1, cout)
         s3 = ops.nchw_to_tokens_x3(x, None, None, conv.cin_pad)
-        out, ho, wo = conv.forward(s3, Fr, H, W, out_f32=True)
+        out, ho, wo = conv.forward(s3, Fr, H, W, split3=True, out_f32=True)          # the layout is stated by the caller, never inferred from the width
         e3 = ((out[:, :cout] - refm).pow(2).mean().sqrt() / refm.pow(2).mean().sqrt()).item()
         out16, _, _ = conv.forward(ops.nchw_to_tokens(x, None, None, conv.cin_pad), Fr, H, W, out_f32=True)
         e1 = ((out16[:, :cout] - refm).pow(2).mean().sqrt() / refm.pow(2).mean().sqrt()).item()

