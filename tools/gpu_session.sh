@@ -41,6 +41,7 @@ for step in "$@"; do
     bench16)  timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --residual-stream 16 > $O/bench6_stream16_rim.json 2>/dev/null; cut -c50-75 $O/bench6_stream16_rim.json
               timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --residual-stream 16 --no-exact-rim > $O/bench6_all16.json 2>/dev/null; cut -c50-75 $O/bench6_all16.json
               timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_default.json 2>/dev/null; cut -c50-75 $O/bench6_default.json ;;
+    fullshare4) SVD_BENCH_SHARE_GPU=1 timeout 1200 python bench.py --workload full --gpus 4 --parallelism job --denoise-steps 2 --steps 1 --warmup 0 --no-trace --no-cpu-baseline > $O/bench_full_4rank_job_shared_gpu.json 2>$O/fullshare4.err; cut -c1-200 $O/bench_full_4rank_job_shared_gpu.json; grep -o '"parallelism": {[^}]*}' $O/bench_full_4rank_job_shared_gpu.json | cut -c1-900; tail -2 $O/fullshare4.err ;;
     fullshare2) SVD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --workload full --gpus 2 --denoise-steps 2 --steps 1 --warmup 0 --no-trace --no-cpu-baseline > $O/bench_full_2rank_shared_gpu.json 2>$O/fullshare2.err; cut -c1-200 $O/bench_full_2rank_shared_gpu.json; grep -o '"parallelism": {[^}]*}' $O/bench_full_2rank_shared_gpu.json | cut -c1-600; tail -2 $O/fullshare2.err ;;
     norms)    timeout 200 python tools/norm_bench.py > $O/norm_bandwidth_after.txt 2>$O/norm_after.err
               grep -h "layernorm\|gn_stats" $O/norm_bandwidth_after.txt | head -12 ;;
@@ -79,6 +80,7 @@ for step in "$@"; do
               grep -E "^\[|passed|failed|FAILED" $O/gpu_tests_full.log | grep -v "Gloo\|W924\|c10d" > $O/gpu_test_lines.txt; tail -1 $O/gpu_test_lines.txt; grep -A42 "slowest 40 durations" $O/gpu_tests_full.log > $O/gpu_test_durations.txt; head -14 $O/gpu_test_durations.txt
               (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -i "smoke") > $O/smoke.txt; cat $O/smoke.txt ;;
     pmc)      bash tools/pmc_round4.sh $O ;;
+    pmcff)    bash tools/pmc_ff.sh $O ;;
     *)        echo "unknown step $step" ;;
   esac
   echo "   ($step: $(( $(date +%s) - t0 )) s)"
