@@ -265,15 +265,22 @@ def run_enhance(args, rank, world, device):
     n_inf = args.denoise_steps or 30
     enh = I2VEnhancer(unet, DDIMSchedule(), guidance_scale=9.0, num_inference_steps=n_inf, strength=0.97)
     n_steps = len(DDIMSchedule().get_timesteps(n_inf, 0.97))
-    group = None
+    group = eplan = None
     if world > 1:
         import torch.distributed as dist
         group = dist.group.WORLD
+        if args.parallelism == "job" and world in (4, 8, 16):
+            # round 5: the stage-1 job plan on the enhancer -- every window on ALL ranks (CFG pair x frame<->pixel sequence parallelism of degree world / 2 inside
+            # I2VGenXLUNet; the 90x160 .. 12x20 levels and the 38 frames split over 2 / 4 / 8 ranks); the default stays the (window, CFG half) units
+            eplan = parallel.JobPlan.from_env(world, "job", frames_cond=chunk, min_pix=240)
+            if eplan.mode != "job" or eplan.sp is None:
+                eplan = None
 
     def one():
         import random
         with torch.no_grad():
-            return enh.denoise(video, noise, conds, chunk, overlap, rng=random.Random(33), group=group)
+            kw = dict(plan=eplan) if eplan is not None else dict(group=group)
+            return enh.denoise(video, noise, conds, chunk, overlap, rng=random.Random(33), **kw)
 
     def sync_all():
         torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
@@ -299,7 +306,8 @@ def run_enhance(args, rank, world, device):
             "config": {"workload": ("I2VGen-XL enhancement (SDEdit): %d blending window(s) of 38 frames @ latent 90x160, overlap %d, CFG 9 (batch 2x38 per window), "
                                     "%d DDIM steps" % (n_win, overlap, n_steps)),
                        "frames_per_step": n_frames, "denoise_steps": n_steps, "latent": [H, W],
-                       "parallelism": (f"{2 * n_win} (window, CFG half) units round-robin over {world} GPUs, one all-gather of the units' predictions per DDIM step"
+                       "parallelism": ((f"every window on all {world} GPUs: CFG pair x frame<->pixel sequence parallelism of degree {world // 2} inside I2VGenXLUNet" if eplan is not None else
+                                        f"{2 * n_win} (window, CFG half) units round-robin over {world} GPUs, one all-gather of the units' predictions per DDIM step")
                                        if world > 1 else "single window"),
                        "weights": "seeded random, reference architecture (1.42 B parameters)"},
             "roofline": roof, "cpu_baseline": None}))

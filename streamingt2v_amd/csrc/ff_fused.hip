@@ -264,38 +264,64 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
         const int row = (tile * 128 + wave * 32 + l31);
         if (row < M) {
             const float* bl = (const float*)(smem + FF_LDS_B2) + 4 * hi;
+            // Residual (and blend partner) loads in batches of G, all issued before the first use: written as one load / add / store per fragment the
+            // compiler serialised the epilogue into 40 HBM round trips per tile (one load in flight: ~20 us of a 96-us tile; profiles/r05_ff_fused_epilogue_mlp.txt).
+            // The registers are there: the S^T accumulators and the fragment rings are dead here.
+            constexpr int NE = FF_NO * 4, G = BLEND ? 5 : 10;
+            static_assert(NE % G == 0, "epilogue batches");
 #pragma unroll
-            for (int o = 0; o < FF_NO; ++o)
+            for (int g0 = 0; g0 < NE; g0 += G) {
+                float4 rv[G], sv[BLEND ? G : 1];
+                if constexpr (RES != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ch = 32 * o + 8 * j;
-                    const float4 b = *(const float4*)(bl + ch);
+                    for (int g = 0; g < G; ++g) {
+                        const int ch = 32 * ((g0 + g) >> 2) + 8 * ((g0 + g) & 3) + 4 * hi;
+                        if constexpr (RES == 2) {
+                            rv[g] = *(const float4*)((const float*)R + (int64_t)row * ldr + ch);
+                            if constexpr (BLEND) sv[g] = *(const float4*)((const float*)S + (int64_t)row * lds + ch);
+                        } else {
+                            const uint2 r = *(const uint2*)((const svd_bf16*)R + (int64_t)row * ldr + ch);
+                            rv[g].x = __builtin_bit_cast(float, r.x); rv[g].y = __builtin_bit_cast(float, r.y);
+                            if constexpr (BLEND) {
+                                const uint2 t = *(const uint2*)((const svd_bf16*)S + (int64_t)row * lds + ch);
+                                sv[g].x = __builtin_bit_cast(float, t.x); sv[g].y = __builtin_bit_cast(float, t.y);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int o = (g0 + g) >> 2, j = (g0 + g) & 3;
+                    const int ch = 32 * o + 8 * j + 4 * hi;
+                    const float4 b = *(const float4*)(bl + 32 * o + 8 * j);
                     float4 v = {o_acc[o][4 * j] + b.x, o_acc[o][4 * j + 1] + b.y, o_acc[o][4 * j + 2] + b.z, o_acc[o][4 * j + 3] + b.w};
                     if constexpr (RES == 2) {
-                        const float4 r = *(const float4*)((const float*)R + (int64_t)row * ldr + ch + 4 * hi);
-                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w;
                     } else if constexpr (RES == 1) {
-                        const uint2 r = *(const uint2*)((const svd_bf16*)R + (int64_t)row * ldr + ch + 4 * hi);
-                        v.x += E::lo(r.x); v.y += E::hi(r.x); v.z += E::lo(r.y); v.w += E::hi(r.y);
+                        const uint32_t r0 = __builtin_bit_cast(uint32_t, rv[g].x), r1 = __builtin_bit_cast(uint32_t, rv[g].y);
+                        v.x += E::lo(r0); v.y += E::hi(r0); v.z += E::lo(r1); v.w += E::hi(r1);
                     }
                     if constexpr (BLEND) {
                         const float beta = 1.0f - alpha;
-                        float4 sv;
+                        float4 sw;
                         if constexpr (RES == 2) {
-                            sv = *(const float4*)((const float*)S + (int64_t)row * lds + ch + 4 * hi);
+                            sw = sv[g];
                         } else {
-                            const uint2 r = *(const uint2*)((const svd_bf16*)S + (int64_t)row * lds + ch + 4 * hi);
-                            sv.x = E::lo(r.x); sv.y = E::hi(r.x); sv.z = E::lo(r.y); sv.w = E::hi(r.y);
+                            const uint32_t t0 = __builtin_bit_cast(uint32_t, sv[g].x), t1 = __builtin_bit_cast(uint32_t, sv[g].y);
+                            sw.x = E::lo(t0); sw.y = E::hi(t0); sw.z = E::lo(t1); sw.w = E::hi(t1);
                         }
-                        v.x = alpha * sv.x + beta * v.x; v.y = alpha * sv.y + beta * v.y; v.z = alpha * sv.z + beta * v.z; v.w = alpha * sv.w + beta * v.w;
+                        v.x = alpha * sw.x + beta * v.x; v.y = alpha * sw.y + beta * v.y; v.z = alpha * sw.z + beta * v.z; v.w = alpha * sw.w + beta * v.w;
                     }
                     if constexpr (OUT32) {
-                        *(float4*)((float*)Y + (int64_t)row * ldy + ch + 4 * hi) = v;
+                        *(float4*)((float*)Y + (int64_t)row * ldy + ch) = v;
                     } else {
                         uint2 u; u.x = E::pack(v.x, v.y); u.y = E::pack(v.z, v.w);
-                        *(uint2*)((svd_bf16*)Y + (int64_t)row * ldy + ch + 4 * hi) = u;
+                        *(uint2*)((svd_bf16*)Y + (int64_t)row * ldy + ch) = u;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     svd_wait_dma();          // the ring's last requests (chunks of a tile that does not exist) must not outlive the workgroup's LDS
@@ -305,13 +331,13 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 // Second form (round 5): the same computation on EIGHT waves per workgroup, two per SIMD -- built on the hypothesis that the four-wave kernel above is
 // bound by ONE wave's issue stream (~535 instructions per 60 MFMAs against the ~5 fillers per 32-cycle MFMA gap that MI355X_MICROARCH.md measures as free
-// for one wave per SIMD).  MEASURED: bit-identical and NOT faster (1.39 vs 1.38 ms at M = 460 800) -- the hypothesis is wrong.  What the probe variants of
-// both forms say instead (profiles/r05_ff_fused_probe_8waves.txt): the matrix pipe alone would need 0.56 ms (registers-only MFMA loop: 2.0-2.07 PFLOP/s at
-// the clock the chip holds); with DMA, GELU, barrier AND fragment reads stripped the eight-wave kernel still takes 0.83 ms -- the remainder is the tile
-// prologue / epilogue (X, R in, Y out: 1.47 GB that every CU moves at the same time, because all workgroups walk their 14-15 tiles in lock step) -- and the
-// four removed pieces cost 0.16 (LDS-DMA) / 0.09 (GELU) / 0.11 (barrier) / 0.20 ms (fragment reads: 240 KiB of ds_read_b128 per chunk and CU, as much LDS
-// time as the chunk's MFMAs take on the matrix pipe) when removed one at a time.  Deeper fragment prefetch (7 ahead) changes nothing.  The kernel stays in
-// the library as an A/B form (SVD_FF_WAVES=8).  Here a PAIR of waves shares 32 token rows: both hold the rows' X fragments; wave q of the pair computes
+// for one wave per SIMD).  MEASURED: bit-identical and, as first built, NOT faster (1.39 vs 1.38 ms at M = 460 800) -- halving the per-wave stream does not
+// shorten the step.  What the probe variants of both forms say instead (profiles/r05_ff_fused_probe_8waves.txt): the matrix pipe alone would need 0.56 ms
+// (registers-only MFMA loop: 2.0-2.07 PFLOP/s at the clock the chip holds); with DMA, GELU, barrier AND fragment reads stripped the eight-wave kernel still
+// took 0.83 ms -- the remainder was the tile epilogue, whose residual loads the compiler had serialised into one HBM round trip per fragment (batched since:
+// see the epilogue) -- and the four removed pieces cost 0.16 (LDS-DMA) / 0.09 (GELU) / 0.11 (barrier) / 0.20 ms (fragment reads) when removed one at a time.
+// Deeper fragment prefetch (7 ahead) changes nothing; a start de-phasing of the workgroups changes nothing.  With the batched epilogue this form is 5 % ahead of
+// the four-wave one (1.24 vs 1.31 ms) and is the default (SVD_FF_WAVES=4 selects the other).  Here a PAIR of waves shares 32 token rows: both hold the rows' X fragments; wave q of the pair computes
 // S^T of hidden tile q of every chunk (20 MFMAs), gates it, and hands its packed 16-unit GEGLU fragment to the partner through a 1-KiB LDS slot
 // (written before the step's workgroup barrier, read after it); each wave then accumulates ITS half of the output channels (5 tiles of 32) over both
 // hidden tiles (10 MFMAs).  Per wave and chunk: 30 MFMAs, 30 fragment reads, 4 GELU pairs, 9 DMA pieces -- half of the four-wave kernel's stream --
@@ -510,38 +536,64 @@ __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16*
         if (row < M) {
             const int cb = 160 * q + 4 * hi;
             const float* bl = (const float*)(smem + FF_LDS_B2) + cb;
+            // Residual (and blend partner) loads in batches of G, all issued before the first use: written as one load / add / store per fragment the
+            // compiler serialised the epilogue into 40 HBM round trips per tile (one load in flight: ~20 us of a 96-us tile; profiles/r05_ff_fused_epilogue_mlp.txt).
+            // The registers are there: the S^T accumulators and the fragment rings are dead here.
+            constexpr int NE = F8_NO * 4, G = BLEND ? 5 : 10;
+            static_assert(NE % G == 0, "epilogue batches");
 #pragma unroll
-            for (int o = 0; o < F8_NO; ++o)
+            for (int g0 = 0; g0 < NE; g0 += G) {
+                float4 rv[G], sv[BLEND ? G : 1];
+                if constexpr (RES != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ch = 32 * o + 8 * j;
-                    const float4 b = *(const float4*)(bl + ch);
+                    for (int g = 0; g < G; ++g) {
+                        const int ch = 32 * ((g0 + g) >> 2) + 8 * ((g0 + g) & 3) + cb;
+                        if constexpr (RES == 2) {
+                            rv[g] = *(const float4*)((const float*)R + (int64_t)row * ldr + ch);
+                            if constexpr (BLEND) sv[g] = *(const float4*)((const float*)S + (int64_t)row * lds + ch);
+                        } else {
+                            const uint2 r = *(const uint2*)((const svd_bf16*)R + (int64_t)row * ldr + ch);
+                            rv[g].x = __builtin_bit_cast(float, r.x); rv[g].y = __builtin_bit_cast(float, r.y);
+                            if constexpr (BLEND) {
+                                const uint2 t = *(const uint2*)((const svd_bf16*)S + (int64_t)row * lds + ch);
+                                sv[g].x = __builtin_bit_cast(float, t.x); sv[g].y = __builtin_bit_cast(float, t.y);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int o = (g0 + g) >> 2, j = (g0 + g) & 3;
+                    const int ch = 32 * o + 8 * j + cb;
+                    const float4 b = *(const float4*)(bl + 32 * o + 8 * j);
                     float4 v = {o_acc[o][4 * j] + b.x, o_acc[o][4 * j + 1] + b.y, o_acc[o][4 * j + 2] + b.z, o_acc[o][4 * j + 3] + b.w};
                     if constexpr (RES == 2) {
-                        const float4 r = *(const float4*)((const float*)R + (int64_t)row * ldr + cb + ch);
-                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w;
                     } else if constexpr (RES == 1) {
-                        const uint2 r = *(const uint2*)((const svd_bf16*)R + (int64_t)row * ldr + cb + ch);
-                        v.x += E::lo(r.x); v.y += E::hi(r.x); v.z += E::lo(r.y); v.w += E::hi(r.y);
+                        const uint32_t r0 = __builtin_bit_cast(uint32_t, rv[g].x), r1 = __builtin_bit_cast(uint32_t, rv[g].y);
+                        v.x += E::lo(r0); v.y += E::hi(r0); v.z += E::lo(r1); v.w += E::hi(r1);
                     }
                     if constexpr (BLEND) {
                         const float beta = 1.0f - alpha;
-                        float4 sv;
+                        float4 sw;
                         if constexpr (RES == 2) {
-                            sv = *(const float4*)((const float*)S + (int64_t)row * lds + cb + ch);
+                            sw = sv[g];
                         } else {
-                            const uint2 r = *(const uint2*)((const svd_bf16*)S + (int64_t)row * lds + cb + ch);
-                            sv.x = E::lo(r.x); sv.y = E::hi(r.x); sv.z = E::lo(r.y); sv.w = E::hi(r.y);
+                            const uint32_t t0 = __builtin_bit_cast(uint32_t, sv[g].x), t1 = __builtin_bit_cast(uint32_t, sv[g].y);
+                            sw.x = E::lo(t0); sw.y = E::hi(t0); sw.z = E::lo(t1); sw.w = E::hi(t1);
                         }
-                        v.x = alpha * sv.x + beta * v.x; v.y = alpha * sv.y + beta * v.y; v.z = alpha * sv.z + beta * v.z; v.w = alpha * sv.w + beta * v.w;
+                        v.x = alpha * sw.x + beta * v.x; v.y = alpha * sw.y + beta * v.y; v.z = alpha * sw.z + beta * v.z; v.w = alpha * sw.w + beta * v.w;
                     }
                     if constexpr (OUT32) {
-                        *(float4*)((float*)Y + (int64_t)row * ldy + cb + ch) = v;
+                        *(float4*)((float*)Y + (int64_t)row * ldy + ch) = v;
                     } else {
                         uint2 u; u.x = E::pack(v.x, v.y); u.y = E::pack(v.z, v.w);
-                        *(uint2*)((svd_bf16*)Y + (int64_t)row * ldy + cb + ch) = u;
+                        *(uint2*)((svd_bf16*)Y + (int64_t)row * ldy + ch) = u;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     svd_wait_dma();
@@ -555,7 +607,7 @@ extern "C" int64_t svd_ff_fused_pack_bytes(int32_t hidden) { return hidden > 0 &
 
 #ifdef SVD_FF_PROBES
 extern "C" { int svd_ff_probe_variant = 0; }      // 1..4 / 101..116: timing probes of the four- / eight-wave kernel; -1: the four-wave kernel; 0: the eight-wave kernel
-#define FF_FORCE4 && svd_ff_probe_variant == -1
+#define FF_FORCE4 || svd_ff_probe_variant == -1
 #else
 #define FF_FORCE4
 #endif
@@ -578,10 +630,11 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
     }
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     const int nch = hidden / 32;
-    // SVD_FF_WAVES=8 (A/B switch): the eight-wave form (wave pairs, two per SIMD) instead of the four-wave one.  Bit-identical results, and the same
-    // time to the per cent (profiles/r05_ff_fused_probe_8waves.txt: 1.39 vs 1.38 ms at M = 460 800, stage-1 line 2.2823 vs 2.2824 frames/s): the default
-    // stays the form every parity number of the round was measured on.
-    static const bool four_waves = [] { const char* e = getenv("SVD_FF_WAVES"); return !(e && e[0] == '8'); }();
+    // SVD_FF_WAVES=4 (A/B switch): the four-wave form (one wave per SIMD) instead of the eight-wave one (wave pairs, two per SIMD).  The two are
+    // bit-identical.  Before the epilogue's residual loads were batched they were equally fast (1.39 vs 1.38 ms at M = 460 800, stage-1 line 2.2823 vs 2.2824
+    // frames/s); with the batched epilogue the eight-wave form is ahead (1.24 vs 1.31 ms; same-box stage-1 line 2.336 vs 2.318, AR chunk 7.48 vs 7.53 s:
+    // profiles/r05_ff_fused_probe_epilogue_mlp.txt, r05_bench6_ff_waves_ab.txt) and is the default.
+    static const bool four_waves = [] { const char* e = getenv("SVD_FF_WAVES"); return e && e[0] == '4'; }();
 #define FF_LAUNCH(RES, OUT)  FF_LAUNCH2(RES, OUT, false)
 #define FF_LAUNCH2(RES, OUT, BL)                                                                                                            \
     do {                                                                                                                                 \
