@@ -64,6 +64,8 @@ def main(db, wl_path, out=None):
             label = b
             if b in ("layernorm_kernel", "layernorm_packed_kernel"):          # one work-log entry (ops.layernorm) covers both forms of the kernel
                 key, label = "layernorm_kernel", "layernorm_kernel + layernorm_packed_kernel"
+            if b in ("ff_geglu_fused_kernel", "ff_geglu_fused8_kernel"):     # one work-log entry (ops.ff_geglu_fused) covers the four- and the eight-wave form
+                key, label = "ff_geglu_fused_kernel", "ff_geglu_fused_kernel / ff_geglu_fused8_kernel"
         else:
             _, i, amode, el = key.split("|")
             c = cfgs[int(i)]
