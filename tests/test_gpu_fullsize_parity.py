@@ -25,9 +25,10 @@ oracle/make_golden_i2v_fullarch.py --fullres, the unmodified reference modules o
     + decode of 8 frames at 576x1024: decoded frames 1.30e-3 max / 1.22e-3 mean, latents 2.7e-3 / 1.9e-3.  That is the network's per-evaluation
     deviation (0.76e-3 at sigma 700, where c_out = -1 and the denoised latent IS the network output) multiplied by classifier-free guidance:
     D = D_u + s (D_c - D_u) carries independent errors of both halves, sqrt(s^2 + (s - 1)^2) = 1.6 .. 3.6 for s = 1.5 .. 3.0 over the 25 frames
-    (mean 2.5 -> 1.9e-3 on the latents, exactly what is measured), and the decoder's contraction.  No 16-bit-operand execution can be closer;
-    the bound asserted is the REFERENCE'S OWN fp16-autocast execution of the same chunk (tests/golden/chunk_fullsize_autocast.json,
-    oracle/make_golden_fullsize.py --which chunk_autocast) and, literally, 1.5e-3 on the decoded frames.
+    (mean 2.5 -> 1.9e-3 on the latents, exactly what is measured), and the decoder's contraction.  No 16-bit-operand execution can be closer
+    (the reference's own fp16 autocast deviates 1.42e-3 per evaluation, wrapper_fullsize_autocast.json).  Asserted: 1.5e-3 on the decoded frames,
+    3.2e-3 on the latents -- and, when tests/golden/chunk_fullsize_autocast.json is present (oracle/make_golden_fullsize.py --which chunk_autocast:
+    the REFERENCE'S OWN fp16-autocast execution of the same chunk; hours of CPU), no further from the fp32 run than that.
 """
 import pytest
 import torch
