@@ -3,9 +3,12 @@
 // Replaces the TWO launches of FeedForward (code/models/svd/sgm/modules/attention.py:94-120: GEGLU.proj + gate, then net[2]; diffusers
 // FeedForward(activation_fn="geglu") in the enhancer, code/i2v_enhance/attention.py:414-534) for dim = 320, inner = 1280 -- the level-0 blocks
 // of the VideoUNet / ControlNet / I2VGenXLUNet, where the [M, 1280] hidden tensor is the largest byte-mover of a forward (1.18 GB written by
-// the projection and read straight back by the down-projection at M = 460 800).  Here the hidden tile never leaves the CU:
+// the projection and read straight back by the down-projection at M = 460 800).  Here the hidden tile never leaves the CU.  Two bit-identical forms of
+// the kernel live in this file: ff_geglu_fused_kernel (four waves, one per SIMD: described first) and ff_geglu_fused8_kernel (eight waves: wave PAIRS
+// share the 32 rows and split the hidden tiles / output channels, described at its definition) -- the eight-wave form is the default since the epilogue's
+// residual loads are batched (1.24 vs 1.31 ms at M = 460 800; SVD_FF_WAVES=4 selects the other).  Common to both:
 //
-//   * one WAVE owns 32 token rows for the whole computation; 4 waves = one 128-row workgroup tile, one wave per SIMD (the accumulators of
+//   * one WAVE (pair) owns 32 token rows for the whole computation; 4 waves = one 128-row workgroup tile, one wave per SIMD (the accumulators of
 //     the full 320-channel output row block are 160 registers per lane);
 //   * the 32 x 320 input rows of the wave stay in 80 VGPRs as the B operands of   S^T[hidden, row] = W1 . X^T   (A = W1 fragments from LDS);
 //     a lane therefore holds, for ITS row, 8 value and the 8 matching gate pre-activations of every 16-hidden MFMA tile (the packed weight

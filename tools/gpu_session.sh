@@ -2,6 +2,8 @@
 # One parametrised lease script (round 4; replaces the per-call r3*.sh files):  gpurun -- 'bash tools/gpu_session.sh <out-dir> <step> [<step> ...]'
 # Every step writes under gpurun_out/<out-dir>/ and is bounded by its own timeout.  Steps:
 #   ffprobe     tools/_bin/ff_fused_probe (round 5: fused feed-forward vs the two-launch path, same process)    i2vparity   tools/i2v_parity.py: enhancer UNet vs the vendored reference per precision plan    paritysigmas   A5 at three sigmas + the 2-step chunk golden
+#   fftest      the fused feed-forward's kernel tests      fsptests   tests/test_gpu_fullsize_parity.py with durations      fixtests   the tests repaired after a suite run      bench6ff / bench6w   same-box bench A/B: SVD_FF_FUSED=1|0, SVD_FF_WAVES=8|4
+#   pmcff       tools/pmc_ff.sh (counters of the fused feed-forward, both forms)      share2 / fullshare2 / fullshare4   bench.py with 2 / 4 ranks on the one leased GPU over gloo (SVD_BENCH_SHARE_GPU=1)
 #   kernels     kernel-level GPU tests (GEMM tiles, norms)                norms       tools/norm_bench.py, packed / one-row LayerNorm and fused / separate GroupNorm finalize
 #   tunear      tools/tune_gemm.py --only ar16 (A/B of kernel variants)      paritysweep   A5 at full size over the precision plans      bench6ab   bench6 with the plan off / default / without the UNet's part
 #   tune        the full tuner (writes streamingt2v_amd/gemm_tiles.json, copied out)
