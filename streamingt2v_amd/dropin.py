@@ -100,3 +100,69 @@ def install_enhancer(pipeline, device="cuda", cfg=None, state_dict=None):
     else:
         pipeline.unet = shell
     return unet
+
+
+class SvdPipelineMirror:
+    """What the reference's `self.svd_pipeline` is called for (code/diffusion_trainer/streaming_svd.py:388-390):
+
+        video_chunks = self.svd_pipeline(image, decode_chunk_size=decode_chunk_size).frames[0]          # list of 25 PIL frames
+
+    i.e. diffusers' StableVideoDiffusionPipeline.__call__ with its defaults (576 x 1024, 25 frames, 25 steps, guidance 1 -> 3, fps 7, motion
+    bucket 127, noise_aug_strength 0.02) -- on libsvdhip.so: `SVDConditioner.first_chunk` + `StreamingSVD._generate_initial_chunk` (the call's
+    semantics, restated in diffusers' own formulation in oracle/svd_pipeline_oracle.py and compared in tests/test_host_svd_cpu.py).  The two
+    random draws follow the pipeline's order: the image's noise augmentation first, then the initial latents (`generator`, else the global stream)."""
+
+    def __init__(self, wrapper, first_stage_model, conditioner, num_frames=25, device="cuda"):
+        from .sampling import EulerEDMSampler
+        from .streaming_svd import StreamingSVD
+        self.num_frames, self.device, self.conditioner = num_frames, device, conditioner
+        self.svd = StreamingSVD(wrapper, first_stage_model, EulerEDMSampler(num_frames=num_frames))
+
+    def __call__(self, image, height=576, width=1024, num_frames=None, num_inference_steps=25, min_guidance_scale=1.0, max_guidance_scale=3.0,
+                 fps=7, motion_bucket_id=127, noise_aug_strength=0.02, decode_chunk_size=None, generator=None, output_type="pil", **_ignored):
+        import types
+        import numpy as np
+        import PIL.Image
+        import torch
+        T = num_frames or self.num_frames
+        assert T == self.num_frames, "the mirror was built for the pipeline's own num_frames"
+        if decode_chunk_size not in (None, 4, 8, T):
+            raise NotImplementedError("decode_chunk_size: the reference passes 8 (4 with memopt)")
+        if isinstance(image, PIL.Image.Image):
+            if image.size != (width, height):
+                image = image.resize((width, height), resample=PIL.Image.LANCZOS)          # VaeImageProcessor.preprocess(resample="lanczos")
+            image = torch.from_numpy(np.asarray(image.convert("RGB")).copy()).permute(2, 0, 1).float() / 255.0
+        img = (image.to(self.device, torch.float32) * 2.0 - 1.0).contiguous()                # [3, H, W] in [-1, 1]
+        cond = self.conditioner
+        cond.fps_id, cond.motion, cond.cond_aug = fps - 1, motion_bucket_id, noise_aug_strength   # "the model was trained on fps - 1"
+        aug = torch.randn((1,) + tuple(img.shape), generator=generator, device=generator.device if generator is not None else "cpu")
+        noise = torch.randn((T, 4, height // 8, width // 8), generator=generator, device=generator.device if generator is not None else "cpu")
+        c, uc = cond.first_chunk(img, aug_noise=aug)
+        self.svd.use_memopt = decode_chunk_size == 4
+        frames = self.svd._generate_initial_chunk(c, uc, noise.to(self.device), num_steps=num_inference_steps, min_scale=min_guidance_scale,
+                                                  max_scale=max_guidance_scale)
+        u8 = ((frames / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float().cpu().numpy() * 255).round().astype("uint8")   # VaeImageProcessor.postprocess "pil"
+        if output_type == "pil":
+            return types.SimpleNamespace(frames=[[PIL.Image.fromarray(f) for f in u8]])
+        return types.SimpleNamespace(frames=[u8])
+
+
+def install_svd_pipeline(model, device="cuda"):
+    """model: the reference's StreamingSVD module with its `svd_pipeline` (diffusers StableVideoDiffusionPipeline.from_pretrained(
+    "stabilityai/stable-video-diffusion-img2vid-xt"), config.yaml:280-299) loaded.  Builds the MI355X networks from the PIPELINE'S OWN weights --
+    `pipe.unet` / `pipe.vae` / `pipe.image_encoder` state dicts through the key maps of diffusers_keys.py (strict) -- and puts a
+    `SvdPipelineMirror` in the pipeline's place, so that the reference's unmodified `image_to_video` (streaming_svd.py:359-402) generates chunk 0
+    on libsvdhip.so with the stock SVD-XT weights.  `svd_pipeline` is a plain attribute (a DiffusionPipeline is not an nn.Module): assignable.
+
+        from streamingt2v_amd import dropin
+        dropin.install(self.model); dropin.install_svd_pipeline(self.model)         # end of inference_i2v.StreamingPipeline.init_model()
+    """
+    from .pipeline import stock_svd_xt_from_state_dicts
+    pipe = model.svd_pipeline
+    cfg = lambda m: dict(getattr(m, "config", {}) or {}) if not hasattr(getattr(m, "config", None), "to_dict") else m.config.to_dict()
+    T = cfg(pipe.unet).get("num_frames", 25)
+    wrapper, fsm, cond = stock_svd_xt_from_state_dicts(pipe.unet.state_dict(), cfg(pipe.unet), pipe.vae.state_dict(), cfg(pipe.vae),
+                                                       pipe.image_encoder.state_dict(), cfg(pipe.image_encoder), device=device, num_frames=T,
+                                                       num_conditional_frames=getattr(getattr(model, "inference_params", None), "num_conditional_frames", 7))
+    model.svd_pipeline = SvdPipelineMirror(wrapper, fsm, cond, num_frames=T, device=device)
+    return model.svd_pipeline

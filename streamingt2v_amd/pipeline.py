@@ -61,22 +61,53 @@ def load_conditioner(state_dict, device="cuda", clip_cfg=None, vae_cfg=None, num
     return SVDConditioner(clip, enc, num_frames=num_frames, generator=generator)
 
 
-def load_stock_svd_xt(folder, device="cuda", variant="fp16", num_frames=25, num_conditional_frames=7, generator=None):
-    """The networks of CHUNK 0 from a diffusers-format ``stabilityai/stable-video-diffusion-img2vid-xt`` folder -- what the reference's
-    ``svd_pipeline`` module is (config.yaml:280-299: StableVideoDiffusionPipeline.from_pretrained(..., torch_dtype=float16, variant="fp16"), called
-    at streaming_svd.py:388-390): unet/ (UNetSpatioTemporalConditionModel = the sgm VideoUNet without ControlNet / CAM, re-keyed), vae/
-    (AutoencoderKLTemporalDecoder = sgm Encoder + VideoDecoder, re-keyed), image_encoder/ (CLIPVisionModelWithProjection).  Returns
-    (StreamingWrapper around the stock UNet, AutoencodingEngineDecoder around the stock decoder, SVDConditioner on the stock towers) for
-    ``StreamingSVD.set_initial_model``.  Key maps: diffusers_keys.py (names restated from diffusers 0.30.2, strict in both directions)."""
-    import json
-    import os
-    from safetensors.torch import load_file
+def stock_svd_xt_from_state_dicts(usd, ucfg, vsd, vcfg, isd, icfg, device="cuda", num_frames=25, num_conditional_frames=7, generator=None):
+    """The three networks of diffusers' StableVideoDiffusionPipeline from their diffusers-named state dicts + config dicts (the values of
+    `pipe.unet.state_dict()` / `pipe.unet.config`, ... or of the folder's safetensors / config.json) -> (StreamingWrapper around the stock UNet,
+    AutoencodingEngineDecoder around the stock decoder, SVDConditioner on the stock towers).  Key maps: diffusers_keys.py (strict both ways)."""
     from .clip_vision import ClipVisionConfig, OpenCLIPVisionTower, hf_clip_vision_to_openclip_keys
     from .conditioner import SVDConditioner
     from .diffusers_keys import svd_unet_diffusers_to_sgm, svd_vae_diffusers_to_sgm
     from .temporal_ae import AutoencodingEngineDecoder, CondFrameEncoder, VaeConfig, VideoDecoder
     from .video_model import UNetConfig, VideoUNet
     from .wrappers import StreamingWrapper
+    g = lambda c, k, d: (c[k] if k in c else d) if isinstance(c, dict) else getattr(c, k, d)
+    boc = tuple(g(ucfg, "block_out_channels", (320, 640, 1280, 1280)))
+    down = g(ucfg, "down_block_types", ("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",))
+    cfg = UNetConfig(in_channels=g(ucfg, "in_channels", 8), model_channels=boc[0], out_channels=g(ucfg, "out_channels", 4),
+                     num_res_blocks=g(ucfg, "layers_per_block", 2), channel_mult=tuple(c // boc[0] for c in boc),
+                     attention_resolutions=tuple(2 ** i for i, t in enumerate(down) if t.startswith("CrossAttn"))[::-1],
+                     context_dim=g(ucfg, "cross_attention_dim", 1024), adm_in_channels=g(ucfg, "projection_class_embeddings_input_dim", 768),
+                     controlnet_mode=False)
+    unet = VideoUNet(cfg)
+    unet.load_state_dict(svd_unet_diffusers_to_sgm(usd, unet.spec(), cfg.num_res_blocks), device=device)
+    vb = tuple(g(vcfg, "block_out_channels", (128, 256, 512, 512)))
+    vae_cfg = VaeConfig(vb[0], tuple(c // vb[0] for c in vb), g(vcfg, "layers_per_block", 2))
+    dec, enc = VideoDecoder(vae_cfg), CondFrameEncoder(vae_cfg)
+    dsd, esd = svd_vae_diffusers_to_sgm(vsd, dec.spec(), enc.spec(), len(vb))
+    dec.load_state_dict(dsd, device=device)
+    enc.load_state_dict(esd, device=device)
+    iv = ClipVisionConfig(width=g(icfg, "hidden_size", 1280), layers=g(icfg, "num_hidden_layers", 32), heads=g(icfg, "num_attention_heads", 16),
+                          patch_size=g(icfg, "patch_size", 14), image_size=g(icfg, "image_size", 224), embed_dim=g(icfg, "projection_dim", 1024),
+                          mlp_ratio=g(icfg, "intermediate_size", 5120) / g(icfg, "hidden_size", 1280))
+    isd = {k: v for k, v in isd.items() if "position_ids" not in k}
+    tower = OpenCLIPVisionTower(iv).load_state_dict(hf_clip_vision_to_openclip_keys(isd, iv.layers), device=device)
+    nf = g(ucfg, "num_frames", num_frames)
+    return (StreamingWrapper(unet, None, num_conditional_frames), AutoencodingEngineDecoder(dec),
+            SVDConditioner(tower, enc, num_frames=nf, generator=generator))
+
+
+def load_stock_svd_xt(folder, device="cuda", variant="fp16", num_frames=25, num_conditional_frames=7, generator=None):
+    """The networks of CHUNK 0 from a diffusers-format ``stabilityai/stable-video-diffusion-img2vid-xt`` folder -- what the reference's
+    ``svd_pipeline`` module is (config.yaml:280-299: StableVideoDiffusionPipeline.from_pretrained(..., torch_dtype=float16, variant="fp16"), called
+    at streaming_svd.py:388-390): unet/ (UNetSpatioTemporalConditionModel = the sgm VideoUNet without ControlNet / CAM, re-keyed), vae/
+    (AutoencoderKLTemporalDecoder = sgm Encoder + VideoDecoder, re-keyed), image_encoder/ (CLIPVisionModelWithProjection).  Returns
+    (StreamingWrapper around the stock UNet, AutoencodingEngineDecoder around the stock decoder, SVDConditioner on the stock towers) for
+    ``StreamingSVD.set_initial_model``.  Key maps: diffusers_keys.py (names restated from diffusers 0.30.2, strict in both directions).
+    Inside the reference itself the same networks come from the loaded pipeline object: dropin.install_svd_pipeline."""
+    import json
+    import os
+    from safetensors.torch import load_file
 
     def part(name, stem):
         d = os.path.join(folder, name)
@@ -87,30 +118,10 @@ def load_stock_svd_xt(folder, device="cuda", variant="fp16", num_frames=25, num_
         raise FileNotFoundError(f"no {stem}[.{variant}].safetensors under {d}")
 
     ucfg, usd = part("unet", "diffusion_pytorch_model")
-    boc = tuple(ucfg.get("block_out_channels", (320, 640, 1280, 1280)))
-    down = ucfg.get("down_block_types", ("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",))
-    cfg = UNetConfig(in_channels=ucfg.get("in_channels", 8), model_channels=boc[0], out_channels=ucfg.get("out_channels", 4),
-                     num_res_blocks=ucfg.get("layers_per_block", 2), channel_mult=tuple(c // boc[0] for c in boc),
-                     attention_resolutions=tuple(2 ** i for i, t in enumerate(down) if t.startswith("CrossAttn"))[::-1],
-                     context_dim=ucfg.get("cross_attention_dim", 1024), adm_in_channels=ucfg.get("projection_class_embeddings_input_dim", 768),
-                     controlnet_mode=False)
-    unet = VideoUNet(cfg)
-    unet.load_state_dict(svd_unet_diffusers_to_sgm(usd, unet.spec(), cfg.num_res_blocks), device=device)
     vcfg, vsd = part("vae", "diffusion_pytorch_model")
-    vb = tuple(vcfg.get("block_out_channels", (128, 256, 512, 512)))
-    vae_cfg = VaeConfig(vb[0], tuple(c // vb[0] for c in vb), vcfg.get("layers_per_block", 2))
-    dec, enc = VideoDecoder(vae_cfg), CondFrameEncoder(vae_cfg)
-    dsd, esd = svd_vae_diffusers_to_sgm(vsd, dec.spec(), enc.spec(), len(vb))
-    dec.load_state_dict(dsd, device=device)
-    enc.load_state_dict(esd, device=device)
     icfg, isd = part("image_encoder", "model")
-    iv = ClipVisionConfig(width=icfg["hidden_size"], layers=icfg["num_hidden_layers"], heads=icfg["num_attention_heads"],
-                          patch_size=icfg["patch_size"], image_size=icfg["image_size"], embed_dim=icfg["projection_dim"],
-                          mlp_ratio=icfg["intermediate_size"] / icfg["hidden_size"])
-    tower = OpenCLIPVisionTower(iv).load_state_dict(hf_clip_vision_to_openclip_keys(isd, iv.layers), device=device)
-    nf = ucfg.get("num_frames", num_frames)
-    return (StreamingWrapper(unet, None, num_conditional_frames), AutoencodingEngineDecoder(dec),
-            SVDConditioner(tower, enc, num_frames=nf, generator=generator))
+    return stock_svd_xt_from_state_dicts(usd, ucfg, vsd, vcfg, isd, icfg, device=device, num_frames=num_frames,
+                                         num_conditional_frames=num_conditional_frames, generator=generator)
 
 
 def load_enhancer(folder, device="cuda", variant="fp16", generator=None):

@@ -218,3 +218,85 @@ def test_initial_chunk_follows_the_diffusers_pipeline(monkeypatch):
     small = torch.rand(1, 3, 100, 100, generator=g)
     assert torch.allclose(kornia_resize_antialias(small, (224, 224), always_blur=True), PO.resize_with_antialiasing(small, (224, 224)), atol=1e-6)
     assert torch.allclose(kornia_resize_antialias(small, (224, 224)), PO.resize_with_antialiasing(small, (224, 224)), atol=1e-6)
+
+
+def test_svd_pipeline_mirror_takes_the_place_of_the_reference_pipeline(monkeypatch):
+    """Row N2, reference side: `dropin.install_svd_pipeline(model)` replaces the reference's `self.svd_pipeline` (diffusers
+    StableVideoDiffusionPipeline) by a mirror built from the PIPELINE'S OWN unet / vae / image_encoder state dicts (diffusers names -> sgm
+    names, strict), and `self.svd_pipeline(image, decode_chunk_size=8).frames[0]` (streaming_svd.py:390) then yields the PIL frames the
+    restated pipeline call (oracle/svd_pipeline_oracle.py, diffusers' formulation) yields on the same two random draws."""
+    import types
+    import numpy as np
+    import PIL.Image
+    svd_shim.install(monkeypatch)
+    pytest.importorskip("transformers")
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle import cases, svd_oracle as O, svd_pipeline_oracle as PO
+    from streamingt2v_amd import dropin
+    from streamingt2v_amd.diffusers_keys import sgm_temporal_decoder_key_to_diffusers as dkey, sgm_unet_key_to_diffusers as ukey
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.temporal_ae import CondFrameEncoder, VaeConfig, VideoDecoder
+    from streamingt2v_amd.video_model import UNetConfig, VideoUNet
+    tu = cases.TINY_UNET
+    T, H, W, steps = 5, 64, 64, 3
+    ucfg = UNetConfig(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"], channel_mult=tu["channel_mult"], controlnet_mode=False)
+    sd_u = init_by_name(VideoUNet(ucfg).spec(), seed=21)
+    vcfg = VaeConfig(32, (1, 1, 1, 2), 1)                                  # 4 levels: latents at 1 / 8 of the image like the shipped VAE
+    sd_d, sd_e = init_by_name(VideoDecoder(vcfg).spec(), seed=22), init_by_name(CondFrameEncoder(vcfg).spec(), seed=23)
+    vae_dif = {}
+    for k, v in sd_d.items():
+        nk = dkey(k, 4)
+        vae_dif[nk] = v[:, :, 0, 0] if "attentions.0.to_" in nk and v.dim() == 4 else v
+    for k, v in sd_e.items():                                              # the encoder half in diffusers' names
+        part, _, r = k.partition(".")
+        if part == "quant_conv":
+            vae_dif[k] = v; continue
+        r = r.replace("norm_out.", "conv_norm_out.").replace("nin_shortcut.", "conv_shortcut.").replace("mid.block_1.", "mid_block.resnets.0.").replace("mid.block_2.", "mid_block.resnets.1.")
+        if r.startswith("mid.attn_1."):
+            r = r.replace("mid.attn_1.", "mid_block.attentions.0.").replace("proj_out.", "to_out.0.").replace("norm.", "group_norm.")
+            for n in "qkv":
+                r = r.replace(f"attentions.0.{n}.", f"attentions.0.to_{n}.")
+            v = v[:, :, 0, 0] if v.dim() == 4 else v
+        if r.startswith("down."):
+            _, i, kind, rest = r.split(".", 3)
+            r = f"down_blocks.{i}.resnets.{rest}" if kind == "block" else f"down_blocks.{i}.downsamplers.0.{rest}"
+        vae_dif["encoder." + r] = v
+
+    class Mod:                                                             # what the mirror reads from a diffusers module: state_dict() and config
+        def __init__(self, sd, config):
+            self._sd, self.config = sd, config
+        def state_dict(self):
+            return self._sd
+    boc = [320 * m for m in tu["channel_mult"]]
+    down = ["CrossAttnDownBlockSpatioTemporal" if (2 ** i) in tu["attention_resolutions"] else "DownBlockSpatioTemporal" for i in range(len(boc))]
+    icfg = dict(hidden_size=320, intermediate_size=1280, num_hidden_layers=1, num_attention_heads=4, image_size=224, patch_size=14, projection_dim=1024)
+    hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_act="gelu", **icfg))
+    hf.config_dict = icfg
+    pipe = types.SimpleNamespace(unet=Mod({ukey(k, ucfg.num_res_blocks): v for k, v in sd_u.items()},
+                                          dict(block_out_channels=boc, layers_per_block=tu["num_res_blocks"], down_block_types=down, num_frames=T)),
+                                 vae=Mod(vae_dif, dict(block_out_channels=[32, 32, 32, 64], layers_per_block=1)),
+                                 image_encoder=Mod({k: v for k, v in hf.state_dict().items()}, icfg))
+    model = types.SimpleNamespace(svd_pipeline=pipe, inference_params=types.SimpleNamespace(num_conditional_frames=tu["Tc"]))
+    mirror = dropin.install_svd_pipeline(model, device="cpu")
+    assert model.svd_pipeline is mirror and mirror.num_frames == T and mirror.conditioner.clip.cfg.layers == 1
+    # the conditioner's two towers are replaced by the linear stand-ins ON BOTH SIDES (the towers themselves are pinned elsewhere; on CPU only their
+    # construction from the pipeline's weights is exercised): what is compared is the call
+    mirror.conditioner.clip, mirror.conditioner.enc = cases.fake_clip_embed, cases.fake_cond_encode
+    rs = np.random.RandomState(3)
+    pil = PIL.Image.fromarray((rs.rand(H, W, 3) * 255).astype("uint8"))
+    with torch.no_grad():
+        out = model.svd_pipeline(pil, decode_chunk_size=8, height=H, width=W, num_inference_steps=steps, generator=torch.Generator().manual_seed(5))
+        frames = out.frames[0]
+        assert len(frames) == T and isinstance(frames[0], PIL.Image.Image) and frames[0].size == (W, H)
+        g = torch.Generator().manual_seed(5)                               # the pipeline's two draws, in its order
+        aug, lat = torch.randn(1, 3, H, W, generator=g), torch.randn(T, 4, H // 8, W // 8, generator=g)
+        image01 = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1)[None].float() / 255.0
+        ocfg = O.Cfg(num_res_blocks=tu["num_res_blocks"], attention_resolutions=tu["attention_resolutions"], channel_mult=tu["channel_mult"])
+        ovae = O.VaeCfg(32, (1, 1, 1, 2), 1)
+        unet_d = PO.sgm_unet_as_diffusers(lambda x, t, ctx, y: O.video_unet(sd_u, ocfg, x, t, ctx, y, T), T)
+        u8, _ = PO.svd_pipeline_call(image01, cases.fake_clip_embed, cases.fake_cond_encode, unet_d, lambda z, num_frames: O.video_decoder(sd_d, ovae, z, num_frames),
+                                     aug_noise=aug, latents=lat[None], num_frames=T, num_inference_steps=steps, decode_chunk_size=8)
+    got = torch.from_numpy(np.stack([np.asarray(f) for f in frames]))
+    lv = (got.int() - u8.int()).abs()
+    print(f"[svd_pipeline mirror vs the restated pipeline call] uint8 frames: {100 * (lv > 0).float().mean():.3f} % of bytes differ, max {int(lv.max())} level")
+    assert got.shape == u8.shape and lv.max().item() <= 1 and (lv > 0).float().mean().item() < 5e-3
