@@ -291,21 +291,24 @@ def _ff_unpack(img, hidden, C, esize, dtype):
     bias = img[:, 2 * NS * fb:2 * NS * fb + 256].contiguous().view(torch.float32).view(nch, 2, 32)
     f2 = img[:, 2 * NS * fb + 1024:].contiguous().view(dtype).view(nch, 2, NO, 64, 8).float()
     w1 = torch.zeros(2 * hidden, C); b1 = torch.zeros(2 * hidden); w2 = torch.zeros(C, hidden)
-    for c in range(nch):
-        for t in range(2):
-            for l in range(64):
-                m, kg = l & 31, l >> 5
-                hid = 32 * c + 16 * t + (m & 15)
-                row = hid if m < 16 else hidden + hid
-                for s_ in range(NS):
-                    w1[row, 16 * s_ + 8 * kg:16 * s_ + 8 * kg + 8] = f1[c, s_, t, l]
-                for o in range(NO):
-                    for e in range(8):
-                        u = 4 * kg + e if e < 4 else 8 + 4 * kg + (e - 4)
-                        w2[32 * o + m, 32 * c + 16 * t + u] = f2[c, t, o, l, e]
-            for m in range(32):
-                hid = 32 * c + 16 * t + (m & 15)
-                b1[hid if m < 16 else hidden + hid] = bias[c, t, m]
+    # scatter by index tensors (one assignment per operand; the element-by-element form of this inverse took ~10 s per layer and made the CPU suite 5x slower):
+    # lane l = (m = l % 32, kg = l / 32); W1 fragment (k-step s, tile t): lane holds row m of the tile (16 value rows, then the 16 gate rows of hidden
+    # 32 c + 16 t ..), channels 16 s + 8 kg .. + 7;  W2 fragment (tile t, output tile o): lane holds output channel 32 o + m, hidden units 4 kg + e (e < 4) /
+    # 8 + 4 kg + (e - 4) of the tile
+    ar = torch.arange
+    c5, l5, e5 = ar(nch).view(-1, 1, 1, 1, 1), ar(64).view(1, 1, 1, -1, 1), ar(8).view(1, 1, 1, 1, -1)
+    m5, kg5 = l5 & 31, l5 >> 5
+    s5, t5 = ar(NS).view(1, -1, 1, 1, 1), ar(2).view(1, 1, -1, 1, 1)                            # f1 index order [c, s, t, l, e]
+    hid = 32 * c5 + 16 * t5 + (m5 & 15)
+    row = torch.where(m5 < 16, hid, hidden + hid) + 0 * (s5 + e5)
+    col = 16 * s5 + 8 * kg5 + e5 + 0 * (c5 + t5)
+    w1[row.expand_as(f1), col.expand_as(f1)] = f1
+    t5b, o5 = ar(2).view(1, -1, 1, 1, 1), ar(NO).view(1, 1, -1, 1, 1)                            # f2 index order [c, t, o, l, e]
+    u5 = torch.where(e5 < 4, 4 * kg5 + e5, 8 + 4 * kg5 + (e5 - 4))
+    w2[(32 * o5 + m5 + 0 * (c5 + t5b + e5)).expand_as(f2), (32 * c5 + 16 * t5b + u5 + 0 * o5).expand_as(f2)] = f2
+    c3, t3, m3 = ar(nch).view(-1, 1, 1), ar(2).view(1, -1, 1), ar(32).view(1, 1, -1)
+    hb = 32 * c3 + 16 * t3 + (m3 & 15)
+    b1[torch.where(m3 < 16, hb, hidden + hb)] = bias
     return w1, b1, w2
 
 
