@@ -152,7 +152,10 @@ def chunk():
 def chunk_autocast():
     """round 5: the SAME chunk with the network evaluations under torch.autocast("cpu", float16) -- the reference's shipped `precision: 16-mixed`
     (config.yaml:8); sampler state and decode in fp32 as the reference runs them (config.yaml:310) -- compared with its own fp32 chunk
-    (tests/golden/chunk_fullsize.pt): the envelope the full-size chunk test is anchored to -> tests/golden/chunk_fullsize_autocast.json"""
+    (tests/golden/chunk_fullsize.pt): the envelope the full-size chunk test is anchored to -> tests/golden/chunk_fullsize_autocast.json
+    COST: fp16 autocast on CPU is far slower than the 807 s per forward measured for a single evaluation in round 2 -- in round 5 two runs in the 8-core
+    build container were stopped after 3 h and 5.3 h (680 CPU-minutes) without reaching the end; the file is therefore not committed and the GPU test
+    falls back to its literal bounds (tests/test_gpu_fullsize_parity.py::test_chunk_full_size_vs_reference)."""
     import json
     from models.svd.sgm.modules.diffusionmodules.denoiser import Denoiser
     from models.svd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
