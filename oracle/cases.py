@@ -329,6 +329,23 @@ def fullsize_chunk_inputs():
     return dict(noise=torch.randn(T, 4, h, w, generator=g), c=cond, uc=uc, ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
 
 
+# Round 6: a WHOLE autoregressive chunk at the shipped size -- 30 AYS steps, all 25 frames decoded -- and the chunk after it, whose ctrl_frames are the
+# last 7 DECODED frames of the first (streaming_svd.py:329-349).  The goldens come from oracle/make_golden_fullsize_gpu.py (the pinned restatement on the GPU
+# box with stock PyTorch ops: the reference needs hours per chunk on CPU and cannot travel).  Fresh draws of every input; noise2 is the second chunk's noise.
+FULLSIZE_CHUNK30_CASE = dict(steps=30, seed=7878)
+
+
+def fullsize_chunk30_inputs():
+    g = _gen(FULLSIZE_CHUNK30_CASE["seed"])
+    c = FULLSIZE_CASE
+    T, h, w = c["T"], c["h"], c["w"]
+    cond = dict(concat=torch.randn(1, 4, h, w, generator=g).mul(0.8).repeat(T, 1, 1, 1), crossattn=torch.randn(1, 1, 1024, generator=g).repeat(T, 1, 1),
+                vector=(torch.randn(1, 768, generator=g) * 0.5).repeat(T, 1))
+    uc = dict(concat=torch.zeros(T, 4, h, w), crossattn=torch.zeros(T, 1, 1024), vector=cond["vector"].clone())
+    return dict(noise=torch.randn(T, 4, h, w, generator=g), noise2=torch.randn(T, 4, h, w, generator=g), c=cond, uc=uc,
+                ctrl_frames=torch.rand(1, c["Tc"], 3, 8 * h, 8 * w, generator=g) * 2 - 1)
+
+
 # Round 5: the enhancer UNet at its shipped configuration AND latent size (90 x 160 = 720 x 1280 pixels; N = 14 400 spatial attention),
 # CFG 2 x 4 frames (oracle/make_golden_i2v_fullarch.py --fullres)
 I2V_FULLRES_CASE = dict(F=4, h=90, w=160, text_tokens=77, seed=6)

@@ -19,18 +19,29 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+# Execution hooks (round 6).  The restatement is device-agnostic: every tensor it creates lives on its inputs' device, so the same functions
+# run on CPU (tests, golden checks) and -- for oracle/make_golden_fullsize_gpu.py only -- on a GPU with STOCK PyTorch ops.  That generator swaps
+# these three entry points for forms that do not depend on MIOpen's / SDPA's backend choice (im2col + matmul convolutions, explicit softmax
+# attention in frame batches); on CPU they are the library calls the reference makes.
+conv2d = F.conv2d
+conv3d = F.conv3d
+sdpa = F.scaled_dot_product_attention
+
 
 # ---- small pieces ---------------------------------------------------------------------------------------------
 def timestep_embedding(t, dim, max_period=10000):
     """models/svd/sgm/modules/diffusionmodules/util.py:207-231  ([cos | sin])."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t[:, None].float() * freqs[None]
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
-def _gn(sd, p, x, eps):
-    return F.group_norm(x.float(), 32, sd[p + ".weight"], sd[p + ".bias"], eps)
+def _gn(sd, p, x, eps, cast_back=False):
+    """cast_back: GroupNorm32 (util.py:274-276: ``super().forward(x.float()).type(x.dtype)``) -- a no-op in fp32, the reference's rounding point
+    under its shipped fp16 autocast; plain nn.GroupNorm (attention.py:132-135, conditioning.py:33-34, model.py:52-55) has none."""
+    y = F.group_norm(x.float(), 32, sd[p + ".weight"], sd[p + ".bias"], eps)
+    return y.type(x.dtype) if cast_back else y
 
 
 def _lin(sd, p, x, bias=True):
@@ -46,7 +57,7 @@ def _mha(q, k, v, heads):
     B, N, C = q.shape
     d = C // heads
     q, k, v = (t.view(B, t.shape[1], heads, d).transpose(1, 2) for t in (q, k, v))
-    o = F.scaled_dot_product_attention(q, k, v)
+    o = sdpa(q, k, v)
     return o.transpose(1, 2).reshape(B, N, C)
 
 
@@ -71,20 +82,25 @@ def alpha_of(sd, name):
     return torch.sigmoid(sd[name])
 
 
+def _blend(a, x_spatial, x_temporal):
+    """AlphaBlender.forward, util.py:366-369: alpha.to(x_spatial.dtype) * x_spatial + (1 - alpha).to(x_spatial.dtype) * x_temporal."""
+    return a.to(x_spatial.dtype) * x_spatial + (1.0 - a).to(x_spatial.dtype) * x_temporal
+
+
 # ---- ResBlocks ------------------------------------------------------------------------------------------------
 def res_block(sd, p, x, emb, dims=2, exchange_temb_dims=False, eps=1e-5):
     """ResBlock._forward, openaimodel.py:328-354 (no up/down, no scale-shift norm)."""
-    conv = F.conv2d if dims == 2 else F.conv3d
+    conv = conv2d if dims == 2 else conv3d
     pad = 1 if dims == 2 else (1, 0, 0)
-    h = conv(F.silu(_gn(sd, p + "in_layers.0", x, eps)), sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=pad)
+    h = conv(F.silu(_gn(sd, p + "in_layers.0", x, eps, True)), sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=pad)
     if emb is not None:
-        e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
+        e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"]).type(h.dtype)      # openaimodel.py:341
         while e.dim() < h.dim():
             e = e[..., None]
         if exchange_temb_dims:
             e = e.transpose(1, 2)            # "b t c ... -> b c t ..."
         h = h + e
-    h = conv(F.silu(_gn(sd, p + "out_layers.0", h, eps)), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=pad)
+    h = conv(F.silu(_gn(sd, p + "out_layers.0", h, eps, True)), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=pad)
     if (p + "skip_connection.weight") in sd:
         x = conv(x, sd[p + "skip_connection.weight"], sd[p + "skip_connection.bias"])
     return x + h
@@ -97,7 +113,7 @@ def video_res_block(sd, p, x, emb, T):
     x5 = x.view(BT // T, T, C, H, W).transpose(1, 2)                       # (b t) c h w -> b c t h w
     xt = res_block(sd, p + "time_stack.", x5, emb.view(BT // T, T, -1), dims=3, exchange_temb_dims=True)
     a = alpha_of(sd, p + "time_mixer.mix_factor")
-    out = a * x5 + (1.0 - a) * xt                                            # alpha * spatial + (1-alpha) * temporal
+    out = _blend(a, x5, xt)                                                  # alpha * spatial + (1-alpha) * temporal
     return out.transpose(1, 2).reshape(BT, C, H, W)
 
 
@@ -140,13 +156,13 @@ def spatial_video_transformer(sd, p, x, context, T):
     time_context = context[::T].repeat_interleave(H * W, dim=0)             # video_attention.py:281-285
     h = _gn(sd, p + "norm", x, 1e-6).flatten(2).transpose(1, 2)             # b c h w -> b (h w) c
     h = _lin(sd, p + "proj_in", h)
-    t_emb = timestep_embedding(torch.arange(T).repeat(BT // T), C)
+    t_emb = timestep_embedding(torch.arange(T, device=x.device).repeat(BT // T), C)
     emb = F.linear(F.silu(F.linear(t_emb, sd[p + "time_pos_embed.0.weight"], sd[p + "time_pos_embed.0.bias"])),
                    sd[p + "time_pos_embed.2.weight"], sd[p + "time_pos_embed.2.bias"])[:, None, :]
     h = basic_transformer_block(sd, p + "transformer_blocks.0.", h, context, heads)
     h_mix = video_transformer_block(sd, p + "time_stack.0.", h + emb, time_context, T, heads)
     a = alpha_of(sd, p + "time_mixer.mix_factor")
-    h = a * h + (1.0 - a) * h_mix
+    h = _blend(a, h, h_mix)
     h = _lin(sd, p + "proj_out", h)
     return h.transpose(1, 2).reshape(BT, C, H, W) + x_in
 
@@ -194,7 +210,7 @@ def _encoder(sd, cfg, h, emb, context, T, after_stem=None):
     """input_blocks loop shared by VideoUNet.forward (video_model.py:569-579) and ControlNet.forward
     (controlnet.py:524-538)."""
     hs = []
-    h = F.conv2d(h, sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"], padding=1)
+    h = conv2d(h, sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"], padding=1)
     if after_stem is not None:
         h = after_stem(h)
     hs.append(h)
@@ -207,7 +223,7 @@ def _encoder(sd, cfg, h, emb, context, T, after_stem=None):
             hs.append(h)
             idx += 1
         if level != len(cfg.mult) - 1:
-            h = F.conv2d(h, sd[f"input_blocks.{idx}.0.op.weight"], sd[f"input_blocks.{idx}.0.op.bias"], stride=2, padding=1)
+            h = conv2d(h, sd[f"input_blocks.{idx}.0.op.weight"], sd[f"input_blocks.{idx}.0.op.bias"], stride=2, padding=1)
             hs.append(h)
             idx += 1
             ds *= 2
@@ -241,23 +257,24 @@ def video_unet(sd, cfg, x, timesteps, context, y, T, hs_control_input=None, hs_c
                 n = 2
             if level and i == cfg.nrb:
                 h = F.interpolate(h, scale_factor=2, mode="nearest")
-                h = F.conv2d(h, sd[f"output_blocks.{idx}.{n}.conv.weight"], sd[f"output_blocks.{idx}.{n}.conv.bias"], padding=1)
+                h = conv2d(h, sd[f"output_blocks.{idx}.{n}.conv.weight"], sd[f"output_blocks.{idx}.{n}.conv.bias"], padding=1)
                 ds //= 2
             idx += 1
-    h = F.silu(_gn(sd, "out.0", h, 1e-5))
-    return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
+    h = h.type(x.dtype)                                                       # video_model.py:617
+    h = F.silu(_gn(sd, "out.0", h, 1e-5, True))
+    return conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
 
 
 def controlnet_cond_embedding(sd, cfg, cond):
     """ControlNetConditioningEmbedding.forward, models/control/controlnet.py:104-121 (LayerNorm over C per pixel)."""
     p = "controlnet_cond_embedding."
-    e = F.silu(F.conv2d(cond, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1))
+    e = F.silu(conv2d(cond, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1))
     nblk = 2 * (len(cfg.cond_embed_channels) - 1)
     for i in range(nblk):
-        e = F.conv2d(e, sd[p + f"blocks.{i}.weight"], sd[p + f"blocks.{i}.bias"], padding=1, stride=2 if i % 2 else 1)
+        e = conv2d(e, sd[p + f"blocks.{i}.weight"], sd[p + f"blocks.{i}.bias"], padding=1, stride=2 if i % 2 else 1)
         e = F.layer_norm(e.permute(0, 2, 3, 1), (e.shape[1],), sd[p + f"norms.{i}.weight"], sd[p + f"norms.{i}.bias"], 1e-5)
         e = F.silu(e.permute(0, 3, 1, 2))
-    return F.conv2d(e, sd[p + "conv_out.weight"], sd[p + "conv_out.bias"], padding=1)
+    return conv2d(e, sd[p + "conv_out.weight"], sd[p + "conv_out.bias"], padding=1)
 
 
 def controlnet(sd, cfg, x, timesteps, controlnet_cond, context, y, T):
@@ -295,10 +312,10 @@ class VaeCfg:
 
 def _ae_resnet(sd, p, x):
     """ResnetBlock.forward with temb=None, diffusionmodules/model.py:131-151."""
-    h = F.conv2d(F.silu(_gn(sd, p + "norm1", x, 1e-6)), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
-    h = F.conv2d(F.silu(_gn(sd, p + "norm2", h, 1e-6)), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    h = conv2d(F.silu(_gn(sd, p + "norm1", x, 1e-6)), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    h = conv2d(F.silu(_gn(sd, p + "norm2", h, 1e-6)), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
     if (p + "nin_shortcut.weight") in sd:
-        x = F.conv2d(x, sd[p + "nin_shortcut.weight"], sd[p + "nin_shortcut.bias"])
+        x = conv2d(x, sd[p + "nin_shortcut.weight"], sd[p + "nin_shortcut.bias"])
     return x + h
 
 
@@ -316,31 +333,31 @@ def _ae_attn(sd, p, x):
     """AttnBlock.forward, diffusionmodules/model.py:180-201 (one head of width C)."""
     B, C, H, W = x.shape
     h = _gn(sd, p + "norm", x, 1e-6)
-    q, k, v = (F.conv2d(h, sd[p + n + ".weight"], sd[p + n + ".bias"]).flatten(2).transpose(1, 2) for n in ("q", "k", "v"))
-    o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    q, k, v = (conv2d(h, sd[p + n + ".weight"], sd[p + n + ".bias"]).flatten(2).transpose(1, 2) for n in ("q", "k", "v"))
+    o = sdpa(q[:, None], k[:, None], v[:, None])[:, 0]
     o = o.transpose(1, 2).reshape(B, C, H, W)
-    return x + F.conv2d(o, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    return x + conv2d(o, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
 
 
 def vae_encoder(sd, cfg, x):
     """Encoder.forward, diffusionmodules/model.py:567-601 (Downsample :73-92: F.pad (0,1,0,1) + stride-2 conv, padding 0).
     x [n, 3, H, W] -> moments [n, 2 * z_channels, H/8, W/8]."""
-    h = F.conv2d(x, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    h = conv2d(x, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
     for lvl in range(len(cfg.ch_mult)):
         for b in range(cfg.nrb):
             h = _ae_resnet(sd, f"down.{lvl}.block.{b}.", h)
         if lvl != len(cfg.ch_mult) - 1:
-            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"down.{lvl}.downsample.conv.weight"], sd[f"down.{lvl}.downsample.conv.bias"], stride=2)
+            h = conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"down.{lvl}.downsample.conv.weight"], sd[f"down.{lvl}.downsample.conv.bias"], stride=2)
     h = _ae_resnet(sd, "mid.block_1.", h)
     h = _ae_attn(sd, "mid.attn_1.", h)
     h = _ae_resnet(sd, "mid.block_2.", h)
     h = F.silu(_gn(sd, "norm_out", h, 1e-6))
-    return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+    return conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
 
 
 def vae_decoder_2d(sd, cfg, z):
     """Decoder.forward (2-D, no temporal layers), diffusionmodules/model.py:715-748; Upsample :52-70 (nearest 2x + conv)."""
-    h = F.conv2d(z, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    h = conv2d(z, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
     h = _ae_resnet(sd, "mid.block_1.", h)
     h = _ae_attn(sd, "mid.attn_1.", h)
     h = _ae_resnet(sd, "mid.block_2.", h)
@@ -348,23 +365,23 @@ def vae_decoder_2d(sd, cfg, z):
         for b in range(cfg.nrb + 1):
             h = _ae_resnet(sd, f"up.{lvl}.block.{b}.", h)
         if lvl != 0:
-            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), sd[f"up.{lvl}.upsample.conv.weight"],
+            h = conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), sd[f"up.{lvl}.upsample.conv.weight"],
                          sd[f"up.{lvl}.upsample.conv.bias"], padding=1)
     h = F.silu(_gn(sd, "norm_out", h, 1e-6))
-    return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+    return conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
 
 
 def cond_frame_encode(sd, cfg, x):
     """AutoencoderKLModeOnly.encode (sgm/models/autoencoder.py:468-490): encoder -> quant_conv -> mode (mean half of the moments)."""
     enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
-    m = F.conv2d(vae_encoder(enc, cfg, x), sd["quant_conv.weight"], sd["quant_conv.bias"])
+    m = conv2d(vae_encoder(enc, cfg, x), sd["quant_conv.weight"], sd["quant_conv.bias"])
     return m[:, : m.shape[1] // 2]
 
 
 def video_decoder(sd, cfg, z, timesteps):
     """VideoDecoder / Decoder.forward, diffusionmodules/model.py:715-748 + temporal_ae.py:291-347, AE3DConv :99-105."""
     T = timesteps
-    h = F.conv2d(z, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    h = conv2d(z, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
     h = _ae_video_res_block(sd, "mid.block_1.", h, T)
     h = _ae_attn(sd, "mid.attn_1.", h)
     h = _ae_video_res_block(sd, "mid.block_2.", h, T)
@@ -373,12 +390,12 @@ def video_decoder(sd, cfg, z, timesteps):
             h = _ae_video_res_block(sd, f"up.{lvl}.block.{b}.", h, T)
         if lvl != 0:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
-            h = F.conv2d(h, sd[f"up.{lvl}.upsample.conv.weight"], sd[f"up.{lvl}.upsample.conv.bias"], padding=1)
+            h = conv2d(h, sd[f"up.{lvl}.upsample.conv.weight"], sd[f"up.{lvl}.upsample.conv.bias"], padding=1)
     h = F.silu(_gn(sd, "norm_out", h, 1e-6))
-    h = F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+    h = conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
     BT, C, H, W = h.shape
     h5 = h.view(BT // T, T, C, H, W).transpose(1, 2)
-    h5 = F.conv3d(h5, sd["conv_out.time_mix_conv.weight"], sd["conv_out.time_mix_conv.bias"], padding=(1, 0, 0))
+    h5 = conv3d(h5, sd["conv_out.time_mix_conv.weight"], sd["conv_out.time_mix_conv.bias"], padding=(1, 0, 0))
     return h5.transpose(1, 2).reshape(BT, C, H, W)
 
 
@@ -424,7 +441,7 @@ def euler_edm_sample(network, x, cond, uc, num_steps, num_frames, min_scale=1.5,
     x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     x = x.float()
     s_in = x.new_ones([x.shape[0]])
-    scale = torch.linspace(min_scale, max_scale, num_frames)
+    scale = torch.linspace(min_scale, max_scale, num_frames, device=x.device)
     for i in range(len(sigmas) - 1):
         sigma, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
         xin = torch.cat([x] * 2)
