@@ -304,6 +304,21 @@ int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t c
                        const void* R, int64_t ldr, const void* S, int64_t lds, float alpha, int32_t res_f32,
                        void* Y, int64_t ldy, int32_t out_f32, int64_t M, int32_t dtype, svd_stream_t stream);
 
+/* Row-owning 320 -> 320 projection of the fp32 residual stream, optionally with the LayerNorm that follows it (ABI v9, round 6):
+ *     V  = R + bias + rowvec[row / rows_per_vec] + X . W^T                  -> Y  (fp32 rows when out_f32, else 16-bit rows; may be NULL when Yn is given)
+ *     Yn = LayerNorm(V; ln_gamma, ln_beta, ln_eps)                          -> 16-bit rows (NULL: no LayerNorm)
+ * Replaces svd_gemm (+ the svd_layernorm behind it) for proj_in / attn1.to_out / proj_out of SpatialVideoTransformer and the attn1.to_out of its
+ * time_stack at dim 320: models/svd/sgm/modules/video_attention.py:260-333,125-168, attention.py:567-593 (norm1 / norm3: attention.py:528-530); the same
+ * projections of the enhancer's Transformer2DModel / TransformerTemporalModel (i2v_enhance/transformer_temporal.py:121-200).  csrc/rowgemm.hip: a wave owns
+ * 32 token rows and all 320 outputs, so the normalisation is lane-local and the fp32 tensor is not re-read.
+ *   X  [M][ldx] 16-bit rows, 320 channels.   Wp: svd_rowgemm320_pack_bytes() bytes, 200 MFMA fragments of W [320 out][320 in] (fragment 10 s + o: lane l holds
+ *      W[32 o + l % 32][16 s + 8 (l / 32) .. + 7]; streamingt2v_amd/video_model.pack_rowgemm320).   bias [320] fp32 or NULL.
+ *   rowvec: per-frame vector rows (fp32, leading dimension rowvec_ld) or NULL; rows_per_vec % 32 == 0.   R: fp32 residual rows or NULL. */
+int64_t svd_rowgemm320_pack_bytes(void);
+int svd_rowgemm320(const svd_bf16* X, int64_t ldx, const void* Wp, const float* bias, const float* rowvec, int32_t rowvec_ld, int32_t rows_per_vec,
+                   const float* R, int64_t ldr, void* Y, int64_t ldy, int32_t out_f32, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                   svd_bf16* Yn, int64_t ldyn, int64_t M, int32_t dtype, svd_stream_t stream);
+
 /* Exact-erf GELU in place on 16-bit rows (nn.GELU of the OpenCLIP ViT-H/14 MLP inside FrozenOpenCLIPImageEmbedder,
  * models/svd/sgm/modules/encoders/modules.py:574-732 -> open_clip transformer.py ResidualAttentionBlock.mlp). */
 int svd_gelu_rows(svd_bf16* X, int64_t ldx, int64_t rows, int32_t channels, int32_t dtype, svd_stream_t stream);

@@ -119,6 +119,31 @@ def i2v_stream_on(channels):
     return I2V_STREAM_F32_MIN_CH > 0 and channels >= I2V_STREAM_F32_MIN_CH
 
 
+# DECODER PRECISION PLAN (round 6): the same two instruments inside the temporal VideoDecoder (temporal_ae.py; code/models/svd/sgm/modules/autoencoding/
+# temporal_ae.py:291-347).  The reference decodes in fp32 (`disable_first_stage_autocast: true`, config.yaml:310): against the fp16-autocast envelope of a whole
+# chunk the decoder's own 16-bit deviation (0.86e-3 per frame) is what put the DECODED frames' mean above the envelope's while the latents were 22 % inside it
+# (profiles/r06_fullsize_chunk_tests.txt).
+#   AE_EXACT_RIM          conv_in (4 -> 512 channels) with split-3 operands, norm_out + SiLU + conv_out (128 -> 3 channels) as the one fp32 head kernel.
+#                         Read at load_state_dict time (together with EXACT_RIM, which packs the split-3 weights).
+#   AE_STREAM_F32_MIN_CH  the fp32 residual stream (ResnetBlock h + skip, the time_stack's alpha blend, AttnBlock x + proj_out) in the blocks with at least this
+#                         many output channels (0 = none).  Read per forward.
+# Environment overrides for A/B runs: SVD_AE_EXACT_RIM, SVD_AE_STREAM_F32_MIN_CH.
+AE_EXACT_RIM = _os.environ.get("SVD_AE_EXACT_RIM", "1") != "0"
+AE_STREAM_F32_MIN_CH = int(_os.environ.get("SVD_AE_STREAM_F32_MIN_CH", "128"))
+
+
+def set_ae_precision_plan(exact_rim=None, stream_f32_min_ch=None):
+    global AE_EXACT_RIM, AE_STREAM_F32_MIN_CH
+    if exact_rim is not None:
+        AE_EXACT_RIM = bool(exact_rim)
+    if stream_f32_min_ch is not None:
+        AE_STREAM_F32_MIN_CH = int(stream_f32_min_ch)
+
+
+def ae_stream_on(channels):
+    return AE_STREAM_F32_MIN_CH > 0 and channels >= AE_STREAM_F32_MIN_CH
+
+
 class stream_scope:
     """with stream_scope(True): the fp32 residual stream is on for the networks evaluated inside (ControlNet.forward_tokens)."""
 
@@ -375,6 +400,45 @@ def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=Fal
         return out
     check(_lib.svd_ff_geglu_fused(*args), "svd_ff_geglu_fused")
     return out
+
+
+# ROW-OWNING 320 -> 320 PROJECTION (round 6, csrc/rowgemm.hip): proj_in / attn1.to_out / proj_out of the 320-channel transformer blocks in ONE launch with the
+# LayerNorm that follows (norm1 / norm3): a wave owns 32 token rows and all 320 outputs, the fp32 tensor the projection writes is not read back by a norm
+# kernel.  SVD_ROWGEMM=0 keeps svd_gemm + svd_layernorm (A/B).
+ROWGEMM = _os.environ.get("SVD_ROWGEMM", "1") != "0"
+
+
+def rowgemm_ok(x, w_img, rows_per_vec=0):
+    """Can `rowgemm320` take this projection?  (320 -> 320, packed weights present, the per-frame vector constant inside a 32-row tile)"""
+    return ROWGEMM and w_img is not None and x.shape[1] == 320 and (rows_per_vec == 0 or rows_per_vec % 32 == 0)
+
+
+def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True):
+    """x [M, 320] 16-bit rows; w_img = video_model.pack_rowgemm320(W) on the device (uint8).  Returns (y, yn): y = residual + bias + rowvec[row // rows_per_vec]
+    + x W^T (fp32 rows when out_f32, else 16 bit; None when want_y is False), yn = LayerNorm(y) * ln[0] + ln[1] in the 16-bit type (None without ln)."""
+    assert x.dtype in (BF16, F16) and x.is_cuda and x.stride(1) == 1 and x.shape[1] == 320 and w_img.dtype == torch.uint8
+    M = x.shape[0]
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(1) == 1 and residual.shape == x.shape
+    if rowvec is not None:
+        assert rowvec.dtype == torch.float32 and rowvec.stride(-1) == 1 and rows_per_vec % 32 == 0 and rows_per_vec > 0
+    assert want_y or ln is not None
+    y = torch.empty((M, 320), dtype=torch.float32 if out_f32 else x.dtype, device=x.device) if want_y else None
+    yn = torch.empty((M, 320), dtype=x.dtype, device=x.device) if ln is not None else None
+    g, b = ln if ln is not None else (None, None)
+    flops = 2.0 * M * 320 * 320
+    nbytes = float(M * 320 * (2 + (4 if residual is not None else 0) + (y.element_size() if y is not None else 0) + (2 if yn is not None else 0)) + w_img.numel())
+    if worklog is not None:
+        _wl("rowgemm320_kernel", flops, nbytes)
+    args = (_p(x), x.stride(0), _p(w_img), _p(bias), _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_vec, _p(residual),
+            residual.stride(0) if residual is not None else 0, _p(y), y.stride(0) if y is not None else 0, int(out_f32), _p(g), _p(b), float(eps),
+            _p(yn), yn.stride(0) if yn is not None else 0, M, _dt(x), _stream())
+    if trace is not None:
+        with trace.launch("rowgemm320", flops=flops, sig=f"rowgemm_M{M}_r{int(residual is not None)}_ln{int(ln is not None)}_o{int(out_f32)}", nbytes=nbytes):
+            check(_lib.svd_rowgemm320(*args), "svd_rowgemm320")
+        return y, yn
+    check(_lib.svd_rowgemm320(*args), "svd_rowgemm320")
+    return y, yn
 
 
 def attn_spatial(q, k, vt, out, frames, n_tok, heads):

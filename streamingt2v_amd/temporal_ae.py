@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .params import Spec, check_state_dict
-from .video_model import _Conv, _dev_bf16, _dev_f32, _sigmoid, pack_conv3x3, pack_tconv3
+from .video_model import _Conv, _dev_bf16, _dev_f32, _sigmoid, pack_conv3x3, pack_tconv3, pad_rows
 
 
 class VaeConfig:
@@ -28,8 +28,9 @@ class VaeConfig:
 class AEVideoResBlock:
     """ResnetBlock (temb=None) -> time_stack ResBlock(3,1,1; no emb) -> alpha*temporal + (1-alpha)*spatial."""
 
-    def __init__(self, prefix, cin, cout):
+    def __init__(self, prefix, cin, cout, stream=False):
         self.p, self.cin, self.cout = prefix, cin, cout
+        self.stream = stream          # may carry the fp32 residual stream (the temporal VideoDecoder's blocks)
 
     def spec(self, s):
         p, ci, co = self.p, self.cin, self.cout
@@ -65,16 +66,22 @@ class AEVideoResBlock:
         cvi = dict(cin=self.cin, hin=H, win=W, hout=H, wout=W, frames=F)
         cv = dict(cin=self.cout, hin=H, win=W, hout=H, wout=W, frames=F)
         tv = dict(cin=self.cout, T=F, pix=pix)
+        # st: this block's sums (h + skip, the alpha blend) are the decoder's residual stream: fp32 between the kernels under the decoder's precision plan
+        # (ops.AE_STREAM_F32_MIN_CH); every convolution operand stays 16 bit.  The block's input is whatever the layer before wrote.
+        st = self.stream and ops.ae_stream_on(self.cout)
         h = ops.groupnorm(x, F, pix, *self.n1, 1e-6, silu=True)
         h = ops.gemm(h, self.w1, bias=self.b1, conv=cvi)
         h = ops.groupnorm(h, F, pix, *self.n2, 1e-6, silu=True)
-        skip = x if self.cin == self.cout else ops.gemm(x, self.ws, bias=self.bs)
-        hs = ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=cv)
+        if self.cin == self.cout:
+            skip = x if (st or x.dtype != torch.float32) else ops.to_elem_rows(x)
+        else:
+            skip = ops.gemm(ops.to_elem_rows(x), self.ws, bias=self.bs, out_f32=st)
+        hs = ops.gemm(h, self.w2, bias=self.b2, residual=skip, conv=cv, out_f32=st)
         g = ops.groupnorm(hs, F, pix, *self.tn1, 1e-5, frames_per_stat=F, silu=True)
         g = ops.gemm(g, self.tw1, bias=self.tb1, temporal=tv)
         g = ops.groupnorm(g, F, pix, *self.tn2, 1e-5, frames_per_stat=F, silu=True)
         # x = alpha * temporal + (1 - alpha) * spatial   (temporal_ae.py:77-78: opposite convention to the UNet)
-        return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(1.0 - self.alpha, hs), temporal=tv)
+        return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, blend=(1.0 - self.alpha, hs), temporal=tv, out_f32=st)
 
 
 class AEAttnBlock:
@@ -103,22 +110,23 @@ class AEAttnBlock:
         c, pix = self.c, H * W
         assert pix % 64 == 0, "VAE mid attention expects H*W to be a multiple of 64"
         h = ops.groupnorm(x, F, pix, *self.n, 1e-6, silu=False)
+        e16 = h.dtype                                                   # x may be the fp32 residual stream: every attention operand is 16 bit
         qk = ops.gemm(h, self.wqk, bias=self.bqk)                       # [F*pix, 2C]
-        key = (F, pix, x.dtype)
+        key = (F, pix, e16)
         vt = self._vt.get(key)
         if vt is None:
-            vt = torch.zeros((F, c, pix), dtype=x.dtype, device=self.dev)
+            vt = torch.zeros((F, c, pix), dtype=e16, device=self.dev)
             self._vt[key] = vt
         ops.gemm(h, self.wv, bias=self.bv, trans_out=dict(tok_per_frame=pix, tokens_ld=pix, out=vt))
-        o = torch.empty((F * pix, c), dtype=x.dtype, device=x.device)
+        o = torch.empty((F * pix, c), dtype=e16, device=x.device)
         s = torch.empty((pix, pix), dtype=torch.float32, device=x.device)
-        p = torch.empty((pix, pix), dtype=x.dtype, device=x.device)
+        p = torch.empty((pix, pix), dtype=e16, device=x.device)
         for f in range(F):
             q_f, k_f = qk[f * pix:(f + 1) * pix, :c], qk[f * pix:(f + 1) * pix, c:]
             ops.gemm(q_f, k_f, out=s)                                    # scores = q k^T  (fp32)
             ops.softmax_rows(s, p, c ** -0.5)
             ops.gemm(p, vt[f], out=o[f * pix:(f + 1) * pix])             # o = P V  (W operand = V^T)
-        return ops.gemm(o, self.wo, bias=self.bo, residual=x)
+        return ops.gemm(o, self.wo, bias=self.bo, residual=x, out_f32=x.dtype == torch.float32)
 
 
 class VideoDecoder:
@@ -130,16 +138,16 @@ class VideoDecoder:
         self.cfg = cfg
         nres = len(cfg.ch_mult)
         block_in = cfg.ch * cfg.ch_mult[-1]
-        self.conv_in = _Conv("conv_in.", cfg.z_channels, block_in)
-        self.mid_block_1 = AEVideoResBlock("mid.block_1.", block_in, block_in)
+        self.conv_in = _Conv("conv_in.", cfg.z_channels, block_in, x3=True)        # rim: split-3 operands under the decoder's precision plan
+        self.mid_block_1 = AEVideoResBlock("mid.block_1.", block_in, block_in, stream=True)
         self.mid_attn_1 = AEAttnBlock("mid.attn_1.", block_in)
-        self.mid_block_2 = AEVideoResBlock("mid.block_2.", block_in, block_in)
+        self.mid_block_2 = AEVideoResBlock("mid.block_2.", block_in, block_in, stream=True)
         self.up = {}
         for lvl in reversed(range(nres)):
             block_out = cfg.ch * cfg.ch_mult[lvl]
             blocks = []
             for b in range(cfg.num_res_blocks + 1):
-                blocks.append(AEVideoResBlock(f"up.{lvl}.block.{b}.", block_in, block_out))
+                blocks.append(AEVideoResBlock(f"up.{lvl}.block.{b}.", block_in, block_out, stream=True))
                 block_in = block_out
             ups = _Conv(f"up.{lvl}.upsample.conv.", block_in, block_in, ups=1) if lvl != 0 else None
             self.up[lvl] = (blocks, ups)
@@ -178,6 +186,14 @@ class VideoDecoder:
         assert self.cfg.out_ch == 3
         self.tmw = _dev_f32(sd["conv_out.time_mix_conv.weight"][:, :, :, 0, 0], device)   # [co, ci, kt]
         self.tmb = _dev_f32(sd["conv_out.time_mix_conv.bias"], device)
+        # decoder precision plan (ops.AE_EXACT_RIM, read here): norm_out + SiLU + conv_out (-> 3 channels) as the fp32 head kernel: weights [tap][c][4]
+        self.head_wt = None
+        if ops.AE_EXACT_RIM and self.final_ch % 32 == 0:
+            wt = torch.zeros(3, 3, self.final_ch, 4, dtype=torch.float32)
+            wt[..., : self.cfg.out_ch] = sd["conv_out.weight"].detach().float().permute(2, 3, 1, 0)
+            self.head_wt = wt.reshape(9, self.final_ch, 4).contiguous().to(device)
+            self.head_b = _dev_f32(pad_rows(sd["conv_out.bias"].detach().float(), 4), device)
+        self.rim_stem = ops.AE_EXACT_RIM and self.conv_in.w3 is not None
         self.device = device
         self.prepared = True
         return self
@@ -186,19 +202,28 @@ class VideoDecoder:
         n, _, H, W = z.shape
         assert timesteps is None or timesteps == n, "one call decodes one temporal group (streaming_svd.py:138-146)"
         F = n
-        h = ops.nchw_to_tokens(z.float().contiguous(), None, None, 32)
-        h, H, W = self.conv_in.forward(h, F, H, W)
+        st = ops.ae_stream_on(self.mid_block_1.cout)
+        if self.rim_stem:
+            h = ops.nchw_to_tokens_x3(z.float().contiguous(), None, None, 32)
+            h, H, W = self.conv_in.forward(h, F, H, W, split3=True, out_f32=st)
+        else:
+            h = ops.nchw_to_tokens(z.float().contiguous(), None, None, 32)
+            h, H, W = self.conv_in.forward(h, F, H, W, out_f32=st)
         h = self.mid_block_1.forward(h, F, H, W)
         h = self.mid_attn_1.forward(h, F, H, W)
         h = self.mid_block_2.forward(h, F, H, W)
-        for lvl in self.up:
+        levels = list(self.up)
+        for i, lvl in enumerate(levels):
             blocks, ups = self.up[lvl]
             for b in blocks:
                 h = b.forward(h, F, H, W)
-            if ups is not None:
-                h, H, W = ups.forward(h, F, H, W)
-        h = ops.groupnorm(h, F, H * W, *self.no, 1e-6, silu=True)
-        h, _, _ = self.conv_out.forward(h, F, H, W, out_f32=True)          # [F*H*W, 4] fp32 (3 valid channels)
+            if ups is not None:        # Upsample.conv output continues the stream when the NEXT level carries it
+                h, H, W = ups.forward(h, F, H, W, out_f32=ops.ae_stream_on(self.up[levels[i + 1]][0][0].cout))
+        if self.head_wt is not None:
+            h = ops.head_gn_silu_conv3x3(h, F, H, W, self.no[0], self.no[1], 1e-6, self.head_wt, self.head_b, self.cfg.out_ch)
+        else:
+            h = ops.groupnorm(h, F, H * W, *self.no, 1e-6, silu=True)
+            h, _, _ = self.conv_out.forward(h, F, H, W, out_f32=True)      # [F*H*W, 4] fp32 (3 valid channels)
         return ops.ae_time_mix3(h, self.tmw, self.tmb, F, H, W, clamp)       # AE3DConv.time_mix_conv -> NCHW fp32
 
 

@@ -95,6 +95,17 @@ def pack_ff_fused(w1, b1, w2):
     return img.view(-1)
 
 
+def pack_rowgemm320(w):
+    """Linear(320, 320) weight [out, in] -> the packed image of svd_rowgemm320 (csrc/rowgemm.hip), a uint8 tensor: 200 MFMA A-operand fragments of 1 KiB,
+    fragment 10 s + o (k-step s of 20, output tile o of 10): lane l holds W[32 o + l % 32][16 s + 8 (l // 32) .. + 7]."""
+    assert tuple(w.shape) == (320, 320)
+    w = w.detach().float().cpu()
+    ar = torch.arange
+    s_, o, l, e = ar(20).view(-1, 1, 1, 1), ar(10).view(1, -1, 1, 1), ar(64).view(1, 1, -1, 1), ar(8).view(1, 1, 1, -1)
+    img = w[32 * o + (l & 31), 16 * s_ + 8 * (l >> 5) + e].to(ops.ELEM).contiguous()
+    return img.view(-1).view(torch.uint8)
+
+
 class FeedForward:
     """FeedForward(dim, mult 4, glu=True) = GEGLU.proj -> value * gelu(gate) -> net[2] (attention.py:94-120; diffusers FeedForward "geglu" in the
     enhancer) on the kernel path: ONE launch of svd_ff_geglu_fused where the fused kernel exists (dim 320: the level-0 blocks, whose [M, 1280]
@@ -327,6 +338,11 @@ class SpatialVideoTransformer:
         self.t_wo, self.t_bo = W(t + "attn1.to_out.0.weight"), Fv(t + "attn1.to_out.0.bias")
         self.t_wv2, self.t_wo2, self.t_bo2 = W(t + "attn2.to_v.weight"), W(t + "attn2.to_out.0.weight"), Fv(t + "attn2.to_out.0.bias")
         self.t_ff = FeedForward(g, t + "ff.", dev)
+        # round 6: the 320 -> 320 projections of the 320-channel blocks in the row-owning kernel's fragment order (ops.rowgemm320, csrc/rowgemm.hip)
+        self.rg = None
+        if self.c == 320:
+            R = lambda k: pack_rowgemm320(g(k)).to(dev)
+            self.rg = dict(pi=R("proj_in.weight"), so=R(b + "attn1.to_out.0.weight"), to=R(t + "attn1.to_out.0.weight"))
         self.tp_w0, self.tp_b0 = W("time_pos_embed.0.weight"), Fv("time_pos_embed.0.bias")
         self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))
@@ -410,17 +426,26 @@ class SpatialVideoTransformer:
                 raise NotImplementedError("cross-attention contexts with > 1 token need use_apm (config.yaml:115 ships use_apm: false)")
             tctx_tokens, ctx = tctx, self._apm_context(ctx)
         h = ops.groupnorm(x, F, pix, self.nw, self.nb, 1e-6, silu=False)
-        h = ops.gemm(h, self.wpi, bias=self.bpi, out_f32=st)
+        # round 6: with the fp32 stream on, a 320-channel block's proj_in / to_out / proj_out run in the row-owning kernel, which also emits the LayerNorm
+        # of its result (norm1 / norm3) -- one launch instead of svd_gemm + svd_layernorm, the fp32 tensor is not read back
+        rg = self.rg if (st and self.rg is not None and x.dtype == torch.float32 and ops.rowgemm_ok(h, self.rg["pi"], pix)) else None
         # ---- spatial BasicTransformerBlock (attention.py:567-593) ----
-        n1 = ops.layernorm(h, *self.s_ln["norm1"])
+        if rg is not None:
+            h, n1 = ops.rowgemm320(h, rg["pi"], bias=self.bpi, ln=self.s_ln["norm1"])
+        else:
+            h = ops.gemm(h, self.wpi, bias=self.bpi, out_f32=st)
+            n1 = ops.layernorm(h, *self.s_ln["norm1"])
         qk = ops.gemm(n1, self.s_wqk)
         vt, tok_ld = self._vt_buf(F, pix, e16)
         ops.gemm(n1, self.s_wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
         a = torch.empty((M, c), dtype=e16, device=x.device)
         ops.attn_spatial(qk[:, :c], qk[:, c:], vt, a, F, pix, heads)
         v2, v2t_c = self._attn2_const(ctx, tctx if tctx_tokens is None else None)                    # attn2 == const/frame
-        h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h, out_f32=st)
-        n3 = ops.layernorm(h, *self.s_ln["norm3"])
+        if rg is not None:
+            h, n3 = ops.rowgemm320(a, rg["so"], bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h, ln=self.s_ln["norm3"])
+        else:
+            h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h, out_f32=st)
+            n3 = ops.layernorm(h, *self.s_ln["norm3"])
         h = self.s_ff(n3, residual=h, out_f32=st)                                     # x_spatial
         # ---- temporal VideoTransformerBlock on the same token layout (video_attention.py:125-168) ----
         # rows (b, t, pixel) with pt pixels per frame: all of them, or this rank's pixel range of ALL T frames (one all-to-all in)
@@ -431,9 +456,13 @@ class SpatialVideoTransformer:
         qkv = ops.gemm(n1, self.t_wqkv)
         at = torch.empty((B * T * pt, c), dtype=e16, device=x.device)
         ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pt, heads)
+        n3 = None
         if tctx_tokens is None:
             v2t = v2t_c                                                                               # [B, C]
-            xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm, out_f32=st)
+            if rg is not None and (T * pt) % 32 == 0:
+                xm, n3 = ops.rowgemm320(at, rg["to"], bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm, ln=self.t_ln["norm3"])
+            else:
+                xm = ops.gemm(at, self.t_wo, bias=self.t_bo, rowvec=v2t, rows_per_vec=T * pt, residual=xm, out_f32=st)
         else:
             # APM: attn2 of the temporal block is a real cross-attention of every (frame, pixel) token to the n_tok context tokens of its
             # batch element (video_attention.py:150-154 with time_context = context[::T] repeated over pixels)
@@ -452,12 +481,15 @@ class SpatialVideoTransformer:
             a2 = torch.empty((B * T * pt, c), dtype=e16, device=x.device)
             ops.attn_cross(q2, k2, vt2, a2, B, T * pt, nt, 1, heads)
             xm = ops.gemm(a2, self.t_wo2, bias=self.t_bo2, residual=xm, out_f32=st)
-        n3 = ops.layernorm(xm, *self.t_ln["norm3"])
+        if n3 is None:
+            n3 = ops.layernorm(xm, *self.t_ln["norm3"])
         xb = self.t_ff(n3, residual=xm, blend=(self.alpha, ht))                                  # AlphaBlender
         if sp is not None:
             xb = sp.to_frames(xb, B, T, pix)                                                    # one all-to-all out
         # xb (the blend) is consumed by proj_out only: a GEMM operand, 16 bit; proj_out + x continues the stream
         out32 = st or (ops.STREAM_F32_SVT_IO_MIN_CH > 0 and c >= ops.STREAM_F32_SVT_IO_MIN_CH)      # (A/B) block output alone in fp32
+        # (proj_out has no LayerNorm behind it: without the fusion the row-owning kernel is no faster than the 256 x 320 tile -- 342 vs 330 us at M = 460 800,
+        #  profiles/r06_rowgemm_probe.txt -- so it stays on svd_gemm)
         return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out_f32=out32)
 
 

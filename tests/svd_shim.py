@@ -329,6 +329,35 @@ def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=Fal
     return y if out_f32 else y.to(x.dtype)
 
 
+def _rowgemm_unpack(img, dtype):
+    """inverse of video_model.pack_rowgemm320: image [20 k-steps, 10 tiles, 64 lanes, 8] -> W [320 out, 320 in] fp32"""
+    f = img.view(dtype).view(20, 10, 64, 8).float()
+    ar = torch.arange
+    s_, o, l, e = ar(20).view(-1, 1, 1, 1), ar(10).view(1, -1, 1, 1), ar(64).view(1, 1, -1, 1), ar(8).view(1, 1, 1, -1)
+    w = torch.zeros(320, 320)
+    w[(32 * o + (l & 31) + 0 * (s_ + e)).expand_as(f), (16 * s_ + 8 * (l >> 5) + e + 0 * o).expand_as(f)] = f
+    return w
+
+
+def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True):
+    """csrc/rowgemm.hip: y = residual + bias + rowvec[row // rows_per_vec] + x W^T; yn = LayerNorm(y) (include/svdhip.h svd_rowgemm320)."""
+    if not hasattr(w_img, "_rg_unpacked"):
+        w_img._rg_unpacked = _rowgemm_unpack(w_img, x.dtype)
+    y = x.float() @ w_img._rg_unpacked.t()
+    if bias is not None:
+        y = y + bias
+    if rowvec is not None:
+        y = y + rowvec[:, :320].repeat_interleave(rows_per_vec, dim=0)[: y.shape[0]]
+    if residual is not None:
+        y = y + residual.float()
+    yn = F.layer_norm(y, (320,), ln[0], ln[1], eps).to(x.dtype) if ln is not None else None
+    return ((y if out_f32 else y.to(x.dtype)) if want_y else None), yn
+
+
+def rowgemm_ok(x, w_img, rows_per_vec=0):
+    return w_img is not None and x.shape[1] == 320 and (rows_per_vec == 0 or rows_per_vec % 32 == 0)
+
+
 def adaptive_avgpool(x, frames, hin, win, hout, wout):
     Cc = x.shape[1]
     y = F.adaptive_avg_pool2d(x.float().view(frames, hin, win, Cc).permute(0, 3, 1, 2), (hout, wout))
@@ -365,7 +394,7 @@ def ddim_cfg_step(x, pred_uncond, pred_cond, guidance_scale, alpha_t, alpha_prev
 
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
          "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3",
-         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder", "ff_geglu_fused", "ddim_cfg_step")
+         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder", "ff_geglu_fused", "ddim_cfg_step", "rowgemm320", "rowgemm_ok")
 
 
 def install(monkeypatch=None):

@@ -153,6 +153,53 @@ def test_ff_geglu_fused(ops, M):
         check(name + " vs fp32 torch", got, ref, 3e-2, 1e-2)
 
 
+@pytest.mark.parametrize("M", [1, 31, 32, 97, 4096, 33000 + 17])
+def test_rowgemm320(ops, M):
+    """svd_rowgemm320 (csrc/rowgemm.hip; the 320 -> 320 projections of SpatialVideoTransformer with the LayerNorm behind them, video_attention.py:260-333,
+    attention.py:528-530,567-593) in every variant the host uses: (1) against the launches it replaces -- svd_gemm (+ fp32 residual, per-frame vector) and
+    svd_layernorm of its fp32 output -- to fp32 summation order / one flipped 16-bit rounding, (2) against plain fp32 PyTorch.  M covers a single row, ragged
+    32-row tiles (the lanes past M store duplicates of row M - 1), many tiles per wave.  An ASYMMETRIC weight catches a transposed fragment."""
+    from streamingt2v_amd.video_model import pack_rowgemm320
+    C = 320
+    x = rnd(M, C, seed=61)
+    w = rnd(C, C, scale=C ** -0.5, seed=62).float().cpu()
+    w[:, :7] *= 3.0; w[5:9] *= 0.25                                       # rows and columns of different scale
+    bias = rnd(C, seed=63, dtype=torch.float32, scale=0.3)
+    g, b = rnd(C, seed=64, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=65, dtype=torch.float32) * 0.1
+    r32 = rnd(M, C, seed=66, dtype=torch.float32)
+    rpv = 32 * 3
+    nvec = (M + rpv - 1) // rpv
+    rv = rnd(nvec, C + 8, seed=67, dtype=torch.float32)[:, :C]             # a row stride that is not the channel count
+    img = pack_rowgemm320(w).cuda()
+    assert img.numel() == ops._lib.svd_rowgemm320_pack_bytes()
+    wd = w.to(BF16).cuda()
+    mm = x.float() @ wd.float().t()
+    for res, vec, ln, out_f32 in [(None, None, True, True), (r32, rv, True, True), (r32, None, False, True), (None, None, False, False), (r32, rv, False, True),
+                                  (None, rv, True, True)]:
+        y, yn = ops.rowgemm320(x, img, bias=bias, rowvec=vec, rows_per_vec=rpv if vec is not None else 0, residual=res, out_f32=out_f32,
+                               ln=(g, b) if ln else None)
+        ref = mm + bias + (res if res is not None else 0) + (vec.repeat_interleave(rpv, 0)[:M] if vec is not None else 0)
+        two = ops.gemm(x, wd, bias=bias, rowvec=vec, rows_per_vec=rpv if vec is not None else 0, residual=res, out_f32=out_f32)
+        name = f"rowgemm320 M={M} res={res is not None} vec={vec is not None} ln={ln} out32={out_f32}"
+        assert y.dtype == two.dtype == (torch.float32 if out_f32 else BF16) and y.shape == (M, C)
+        # fp32 output: summation order only -- plus, with a per-frame vector, its hi + lo 16-bit split (2^-22 relative in fp16, 2^-16 in bf16: |vec| <= 5 here)
+        a32 = 2e-5 + (1e-4 if (vec is not None and BF16 == torch.bfloat16) else 0.0)
+        check(name + " vs svd_gemm", y, two, a32 if out_f32 else 1.2e-2, 2e-5 if out_f32 else 8e-3)
+        check(name + " vs fp32 torch", y, ref, a32 if out_f32 else 1.2e-2, 2e-5 if out_f32 else 8e-3)
+        if ln:
+            assert yn.dtype == BF16 and yn.shape == (M, C)
+            check(name + " LayerNorm vs svd_layernorm(svd_gemm)", yn, ops.layernorm(two, g, b), 1.2e-2, 8e-3)
+            check(name + " LayerNorm vs fp32 torch", yn, F.layer_norm(ref, (C,), g, b, 1e-5), 1.2e-2, 8e-3)
+        else:
+            assert yn is None
+    # LayerNorm only (no Y): the CAM-style use; and run-to-run bit identity (independent waves, no atomics)
+    _, yn1 = ops.rowgemm320(x, img, bias=bias, residual=r32, ln=(g, b), want_y=False)
+    y2, yn2 = ops.rowgemm320(x, img, bias=bias, residual=r32, ln=(g, b))
+    assert torch.equal(yn1, yn2)
+    y3, yn3 = ops.rowgemm320(x, img, bias=bias, residual=r32, ln=(g, b))
+    assert torch.equal(y2, y3) and torch.equal(yn2, yn3)
+
+
 def test_geglu_gate_function_against_exact_erf(ops):
     """The GEGLU epilogue's gate function alone, on every 16-bit gate value in [-9.5, 9.5]: value = 1 (bias only), gate = x through a unit
     weight, so the output is rn16(gelu(x)) -- the exact-erf GELU of the reference's GEGLU (attention.py:99-101) as csrc/svd_common.h

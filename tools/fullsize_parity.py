@@ -84,6 +84,59 @@ def chunk_fullsize(dtype="fp16", device="cuda", sds=None):
     return dict(frames=rf, z=rz)
 
 
+def chunk30_fullsize(dtype="fp16", device="cuda", sds=None, also_chunk2=True):
+    """Round 6: a WHOLE autoregressive chunk at the shipped size -- 30 AYS Euler steps of sampler o denoiser o guider o StreamingWrapper (ControlNet + 13 CAM
+    mergers), decode_first_stage of all 25 frames, clamp (`_generate_conditional_output`, streaming_svd.py:155-221) -- and the chunk AFTER it, whose
+    ctrl_frames are the last 7 frames THIS path decoded (`_autoregressive_generation`, :329-349), against tests/golden/chunk30_fullsize.pt and
+    ar_handover_fullsize.pt (oracle/make_golden_fullsize_gpu.py).  also_chunk2: the round-5 two-step chunk against the reference's own CPU golden
+    (tests/golden/chunk_fullsize.pt) on the same loaded networks.  Returns per-frame L2 dicts: chunk2 / chunk30 / handover, each {frames, z}."""
+    from oracle.cases import (FULLSIZE_CASE as c, FULLSIZE_CHUNK30_CASE as c30, FULLSIZE_CHUNK_CASE as cc, fullsize_chunk30_inputs, fullsize_chunk_inputs,
+                              fullsize_pixel_subset)
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.params import init_by_name
+    from streamingt2v_amd.sampling import EulerEDMSampler
+    from streamingt2v_amd.streaming_svd import StreamingSVD
+    from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VideoDecoder
+    from streamingt2v_amd.wrappers import StreamingWrapper
+    torch.set_grad_enabled(False)
+    ops.set_element_dtype(DT[dtype])
+    sds = {} if sds is None else sds
+    unet, cn = _load_nets(sds, device)
+    dec = VideoDecoder()
+    dec.load_state_dict(init_by_name(dec.spec(), seed=35), device=device)
+    T, Tc = c["T"], c["Tc"]
+    dev = lambda d: {k: v.to(device) for k, v in d.items()}
+    svd = StreamingSVD(StreamingWrapper(unet, cn, Tc), AutoencodingEngineDecoder(dec), sampler=EulerEDMSampler(num_steps=c30["steps"], num_frames=T))
+    res = {}
+    idx16 = fullsize_pixel_subset(576 * 1024)
+    if also_chunk2:
+        gold = torch.load(os.path.join(GOLD, "chunk_fullsize.pt"))
+        inp = fullsize_chunk_inputs()
+        z = svd.sampler(svd.inference_model, inp["noise"].to(device).clone(), dev(inp["c"]), dev(inp["uc"]), num_steps=cc["steps"], batch_size=2,
+                        num_video_frames=T, ctrl_frames=inp["ctrl_frames"].to(device))
+        fr = svd.decode_first_stage(z[:cc["decode_frames"]], clamp=True)
+        res["chunk2"] = dict(frames=frame_errors(fr.float().flatten(2)[:, :, idx16.to(device)], gold["frames_subset"]), z=frame_errors(z, gold["z"]))
+        del gold, fr, z
+    idx = idx16[::2].contiguous().to(device)
+    inp = fullsize_chunk30_inputs()
+    cnd, uc = dev(inp["c"]), dev(inp["uc"])
+    g1, g2 = torch.load(os.path.join(GOLD, "chunk30_fullsize.pt")), torch.load(os.path.join(GOLD, "ar_handover_fullsize.pt"))
+    def chunk(ctrl, noise):          # the body of StreamingSVD._generate_conditional_output, keeping the latents for the report
+        z = svd.sampler(svd.inference_model, noise.to(device).clone().float().contiguous(), cnd, uc, batch_size=2, num_video_frames=T, ctrl_frames=ctrl)
+        return z, svd.decode_first_stage(z, clamp=True)
+    z1, fr1 = chunk(inp["ctrl_frames"].to(device), inp["noise"])
+    res["chunk30"] = dict(frames=frame_errors(fr1.float().flatten(2)[:, :, idx], g1["frames_subset"]), z=frame_errors(z1, g1["z"]))
+    ctrl = StreamingSVD.extract_ctrl_frames(fr1, Tc)                      # the reference's hand-over, from THIS path's own frames
+    res["handover_ctrl"] = frame_errors(ctrl[0].float().flatten(2)[:, :, idx], g2["ctrl_subset"])
+    z2, fr2 = chunk(ctrl, inp["noise2"])
+    torch.cuda.synchronize()
+    res["handover"] = dict(frames=frame_errors(fr2.float().flatten(2)[:, :, idx], g2["frames_subset"]), z=frame_errors(z2, g2["z"]))
+    del unet, cn, dec, svd, fr1, fr2
+    torch.cuda.empty_cache()
+    ops.set_element_dtype(None)
+    return res
+
+
 def wrapper_fullsize(dtype, device="cuda", sds=None, stream_f32=None, timing=False, plan=None, case="sigma7.47"):
     """stream_f32: None = the package default (ops.STREAM_F32), True / False = fp32 / 16-bit residual stream.  timing: also time the forward
     (3 runs after the parity run, device-synchronised) -> res['ms'].  case: which golden / input draw (CASES)."""
