@@ -18,10 +18,10 @@ chunk: the last AR chunk is cut by [:100], inference_i2v.py:190) / max-over-rank
             blending + frame interpolation; value = 200 final frames / end-to-end seconds, per-stage seconds in config.
 Weights: seeded random at the reference's exact architecture (no checkpoints offline; zero-inits un-zeroed).
 Inputs already resident in HBM when the timed region starts.
-Multi-GPU (--gpus N > 1): default --parallelism auto = N/2 independent videos, each on a CFG PAIR of GPUs (the two CFG halves of every
-network call on two ranks, one RCCL all-gather of the 3.7 MB network output per Euler step; SURVEY.md 8e option 1) -- chunks of one video are
-sequential (chunk k+1 needs chunk k's decoded frames), so more videos, not more chunks, fill a node.  --parallelism job: ONE job strong-scaled
-over all GPUs (CFG pair x frame<->pixel sequence parallelism, RCCL all-to-all around the temporal operators; SURVEY 8e options 1 + 2).
+Multi-GPU (--gpus N > 1): default --parallelism auto = job for the job-level workloads: ONE job strong-scaled over all GPUs (CFG pair -- the two CFG
+halves of every network call on two ranks, one RCCL all-gather of the 3.7 MB network output per Euler step -- x frame<->pixel sequence parallelism of
+degree N/2, RCCL all-to-all around the temporal operators; SURVEY 8e options 1 + 2): chunks of one video are sequential (chunk k+1 needs chunk k's
+decoded frames), so a job scales INSIDE a chunk.  --parallelism pairs: N/2 independent videos, each on a CFG pair (throughput; weak scaling beyond 2 GPUs).
 --parallelism replica: one independent video per GPU (no collective).
 
 The JSON line also carries
@@ -129,7 +129,8 @@ def precision_plan():
     """The round-4 precision plan the networks were loaded under (streamingt2v_amd.ops) -- part of every line's config."""
     from streamingt2v_amd import ops
     return {"element": str(ops.ELEM).replace("torch.", ""), "exact_rim": bool(ops.EXACT_RIM), "controlnet_stream_fp32": bool(ops.CN_STREAM_F32),
-            "unet_stream_fp32_min_channels": int(ops.STREAM_F32_MIN_CH), "unet_stream_fp32_everywhere": bool(ops.STREAM_F32)}
+            "unet_stream_fp32_min_channels": int(ops.STREAM_F32_MIN_CH), "unet_stream_fp32_everywhere": bool(ops.STREAM_F32),
+            "decoder_exact_rim": bool(ops.AE_EXACT_RIM), "decoder_stream_fp32_min_channels": int(ops.AE_STREAM_F32_MIN_CH)}
 
 
 def build_models(workload, device):
@@ -171,7 +172,9 @@ def cpu_baseline(workload):
         spatial attention, the 295-MB-class activations and the cache behaviour of the real forward are all in the sample;
       * one frame decoded by the temporal VAE at 576x1024.
     A forward of the job has 50 frames (x 12.5); AR chunks add ControlNet + CAM: x 181.96 / 159.9 algorithmic FLOP.
-    The reference's own modules, timed in the build container: profiles/r02_cpu_reference_forward.txt."""
+    kind "port": the reference is Python and cannot travel to the GPU box in any form, so what is timed HERE is its pinned restatement (same library
+    calls: F.conv2d / F.linear / SDPA / group_norm in fp32).  The reference's own modules were timed once in the 8-core build container
+    (553 s per forward: profiles/r02_cpu_reference_forward.txt); that number is documentation, not part of this line."""
     from oracle import svd_oracle as O
     from streamingt2v_amd.params import init_by_name
     from streamingt2v_amd.temporal_ae import VideoDecoder
@@ -214,9 +217,6 @@ def cpu_baseline(workload):
         enh_s = 29 * win_fwd * (3 + 3 / 38)
         stage1_s = (25 * fwd_c2 + dec_chunk) + 5 * (30 * fwd_ar + dec_chunk)
         return {"value": 180 / (stage1_s + enh_s), "unit": "frames/s", "cores": cores, "kind": "port",
-                "reference_modules_8core_s": {"streaming_wrapper_forward_cfg2x25": 553.0, "video_decoder_per_frame": 28.0,
-                                              "note": "the reference's OWN unmodified modules, fp32, timed once on the 8-core build container (profiles/r02_cpu_reference_forward.txt); "
-                                                      "static: /root/reference does not exist on the GPU box"},
                 "sample": f"stage 1: oracle VideoUNet forward, CFG 2 x {T} frames @ {h}x{w} latent: {t_unet:.1f} s; VideoDecoder 1 frame @ 576x1024: {t_dec:.1f} s "
                           f"=> {stage1_s:.0f} s per 100-frame stage 1; enhancement: oracle I2VGenXLUNet forward, CFG 2 x {Fe} frames @ {he}x{we} latent: {t_enh:.1f} s; "
                           f"x19 over frames => {win_fwd:.0f} s per 38-frame window forward, x 29 DDIM steps x (3 windows + key-frame pre-pass) => {enh_s:.0f} s; "
@@ -228,9 +228,6 @@ def cpu_baseline(workload):
     else:
         chunk_s, frames, what = (25 * fwd_c2 + dec_chunk) + 5 * (30 * fwd_ar + dec_chunk), 100, "100-frame stage 1 (chunk 0 + 5 AR chunks)"
     return {"value": frames / chunk_s, "unit": "frames/s", "cores": cores, "kind": "port",
-            "reference_modules_8core_s": {"streaming_wrapper_forward_cfg2x25": 553.0, "video_decoder_per_frame": 28.0,
-                                          "note": "the reference's OWN unmodified modules, fp32, timed once on the 8-core build container (profiles/r02_cpu_reference_forward.txt); "
-                                                  "static: /root/reference does not exist on the GPU box"},
             "sample": f"oracle VideoUNet forward, CFG 2 x {T} frames @ {h}x{w} latent (full size): {t_unet:.1f} s; VideoDecoder 1 frame @ 576x1024: "
                       f"{t_dec:.1f} s; x12.5 over frames => {fwd_c2:.0f} s per 50-frame forward (x1.138 with ControlNet + CAM), "
                       f"{dec_chunk:.0f} s per 25-frame decode => {chunk_s:.0f} s per {what}"}
@@ -416,6 +413,74 @@ def build_stage1(args, world, device):
     return plan, model, c, uc, noises, g
 
 
+def other_stages(args, device, stage1_s):
+    """The rest of the 200-frame job next to the driver-timed stage-1 number (single GPU, after the timed region, never inside it): ONE 38-frame window of the
+    I2VGen-XL enhancer (29 DDIM steps, CFG 9, latent 90x160; pipeline_i2vgen_xl.py:841-913) with its own launch trace, and EMA-VFI frame pairs at 720x1280.
+    The shipped job enhances 100 frames as 3 windows of 38 (overlap 12) + a 3-frame key-frame pre-pass and interpolates 99 pairs (i2v_enhance_interface.py:86-138,
+    inference_i2v.py:211-224): final_frames_per_s_estimate = 180 delivered frames / (stage 1 + (3 + 3/38) windows + 99 pairs); VAE encode / decode of the enhancer
+    (2 % of the job, profiles/r05_bench_full_pipeline.json) is not in the estimate -- `--workload full` measures the whole job."""
+    import random
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.ema_vfi import EMAVFI, VFIConfig
+    from streamingt2v_amd.enhance import DDIMSchedule, I2VEnhancer
+    from streamingt2v_amd.i2vgen_unet import I2VConfig, I2VGenXLUNet
+    from streamingt2v_amd.params import init_by_name
+    chunk, H, W, cd = 38, 90, 160, 1024
+    unet = I2VGenXLUNet(I2VConfig())
+    unet.load_state_dict(init_by_name(unet.spec(), seed=5, device=device), device=device)
+    g = torch.Generator(device=device); g.manual_seed(33)
+    rn = lambda *sh: torch.randn(*sh, generator=g, device=device)
+    il, emb, text = rn(1, 4, chunk, H, W) * 0.7, rn(1, cd), rn(1, 77, cd)
+    conds = [dict(fps=torch.tensor([38, 38]), image_latents=torch.cat([il, il]), image_embeddings=torch.cat([torch.zeros_like(emb), emb]),
+                  text=torch.cat([torch.zeros_like(text), text]))]
+    video, noise = rn(1, 4, chunk, H, W) * 0.5, rn(1, 4, chunk, H, W)
+    enh = I2VEnhancer(unet, DDIMSchedule(), guidance_scale=9.0, num_inference_steps=30, strength=0.97)
+    n_steps = len(DDIMSchedule().get_timesteps(30, 0.97))
+    with torch.no_grad():
+        warm = I2VEnhancer(unet, DDIMSchedule(), guidance_scale=9.0, num_inference_steps=30, strength=0.1)      # 2 DDIM steps: one-time kernel attributes, caches
+        warm.denoise(video, noise, conds, chunk, 0, rng=random.Random(33))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = enh.denoise(video, noise, conds, chunk, 0, rng=random.Random(33))
+        torch.cuda.synchronize()
+        win_s = time.perf_counter() - t0
+        assert torch.isfinite(out).all()
+        trace = LaunchTrace()
+        ops.trace = trace
+        warm.denoise(video, noise, conds, chunk, 0, rng=random.Random(33))          # traced separately (2 DDIM steps): the timed window above is untraced
+        torch.cuda.synchronize()
+        ops.trace = None
+    eroof = roofline_from_trace(trace)
+    eroof.pop("traced_kernels", None)
+    eroof["traced"] = "2 DDIM steps of the window after the timed one; HIP events around every GEMM / fused-FF / MFMA-attention launch"
+    del unet, enh, warm, out
+    torch.cuda.empty_cache()
+    vfi = EMAVFI(VFIConfig())
+    vfi.load_state_dict(init_by_name(vfi.spec(), seed=3), device=device)
+    fr = [torch.rand(720, 1280, 3, generator=g, device=device) for _ in range(4)]
+    with torch.no_grad():
+        for i in range(2):
+            vfi.inference(fr[i], fr[i + 1], want_uint8=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_pairs = 8
+        for i in range(n_pairs):
+            vfi.inference(fr[i % 4], fr[(i + 1) % 4], want_uint8=True)
+        torch.cuda.synchronize()
+        pair_ms = (time.perf_counter() - t0) / n_pairs * 1e3
+    del vfi
+    torch.cuda.empty_cache()
+    enh_s = win_s * (3.0 + 3.0 / 38.0)
+    vfi_s = 99 * pair_ms * 1e-3
+    return {"enhance_window_s": round(win_s, 3), "enhance_window": f"38 frames @ latent 90x160 (720x1280), {n_steps} DDIM steps, CFG 9 (batch 2 x 38)",
+            "enhance_roofline": eroof, "vfi_pair_ms": round(pair_ms, 2), "vfi_pair": "EMA-VFI fast-TTA interpolation of one 720x1280 frame pair + uint8 conversion",
+            "stage1_s_per_100_frames": round(stage1_s, 2), "enhance_s_estimate": round(enh_s, 2), "vfi_s_estimate": round(vfi_s, 2),
+            "final_frames_per_s_estimate": round(180.0 / (stage1_s + enh_s + vfi_s), 4),
+            "estimate_definition": "180 delivered frames / (stage-1 s per 100 frames + (3 + 3/38) x window s + 99 x pair s): the shipped job's frame arithmetic "
+                                   "(3 blending windows of 38 frames + the 3-frame key-frame pre-pass, 99 interpolated pairs); the enhancer's VAE encode / decode is not counted "
+                                   "(--workload full measures the whole job)"}
+
+
 def run_stage1(args, rank, world, device):
     """Default workload: stage 1 of the 200-frame job, one step = one chunk of the real autoregressive sequence (see the module docstring).
     The warm-up ENDS at a video boundary (the stream starts (-warmup) mod 6 chunks into a video, on stand-in control frames), so the timed
@@ -467,6 +532,12 @@ def run_stage1(args, rank, world, device):
         torch.cuda.synchronize()
         ops.trace = None
         roof = roofline_from_trace(trace)
+    stages = None
+    if not args.no_stages and rank == 0 and world == 1 and t_c0 is not None and t_ar is not None:
+        try:
+            stages = other_stages(args, device, t_c0 + 5.0 * t_ar)
+        except Exception as e:       # the stage-1 measurement above must never be lost to a problem in the side measurement
+            stages = {"error": repr(e)}
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -487,7 +558,7 @@ def run_stage1(args, rank, world, device):
                        "latent": [LAT_H, LAT_W], "denoise_steps": [args.denoise_steps or 25, args.denoise_steps or 30],
                        "parallelism": plan.describe(), "precision_plan": precision_plan(),
                        "weights": "seeded random, reference architecture (1.59 B + 0.67 B + 64 M parameters)"},
-            "roofline": roof, "cpu_baseline": cpu}))
+            "roofline": roof, "cpu_baseline": cpu, "stages": stages}))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -686,7 +757,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 6 = one whole video for stage1, so that both chunk types are warmed; 1 otherwise)")
     ap.add_argument("--workload", default="stage1", choices=["stage1", "c2", "ar_chunk", "c3", "enhance", "vfi", "full"])
     ap.add_argument("--parallelism", default="auto", choices=["auto", "pairs", "job", "replica", "cfg"],
-                    help="auto (default) = pairs on an even number of GPUs, replica otherwise.  pairs: N/2 independent videos, each on a CFG pair of GPUs "
+                    help="auto (default) = job for the stage1 / full workloads on an even number of GPUs (pairs for the chunk-level workloads), replica otherwise.  pairs: N/2 independent videos, each on a CFG pair of GPUs "
                          "(one 2-rank all-gather of the network output per Euler step; the only collectives of the default path); job (stage1 / full): ONE "
                          "job over all GPUs, CFG pair x frame<->pixel sequence parallelism (all-to-all around the temporal operators; strong scaling; "
                          "verified on the HIP kernels with 2 and 4 processes, tests/test_gpu_multiproc.py, never yet run over RCCL on 8 GPUs); replica: one "
@@ -704,10 +775,16 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the per-step network evaluation from a hipGraph captured at the second Euler step of every chunk (sampling.EulerEDMSampler(use_graph=True))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="stage1 workload: skip the enhancer-window / VFI-pair side measurement after the timed region")
     ap.add_argument("--no-trace", action="store_true")
     args = ap.parse_args()
     if args.parallelism == "auto":
-        args.parallelism = "pairs" if (args.gpus > 1 and args.gpus % 2 == 0) else "replica"
+        # round 6: the metric is ONE 200-frame job at 1 / 2 / 4 / 8 GPUs, so the job-level workloads strong-scale one job by default (CFG pair x sequence
+        # parallelism; at N = 2 that IS one CFG pair) -- `--parallelism pairs` is the throughput plan (N/2 independent videos, weak scaling beyond 2 GPUs)
+        if args.gpus > 1 and args.gpus % 2 == 0:
+            args.parallelism = "job" if args.workload in ("stage1", "full") else "pairs"
+        else:
+            args.parallelism = "replica"
     if args.steps is None:
         args.steps = 6 if args.workload == "stage1" else 1
     if args.warmup is None:

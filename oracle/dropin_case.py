@@ -136,6 +136,13 @@ def run(swap, monkeypatch=None, record=None):
             lambda m, args, kwargs, out: record.append(("decoder", [cl(x) for x in args], {k: cl(x) for k, x in kwargs.items()}, cl(out))), with_kwargs=True)
         record.append(("sigmas", [sampler.discretization(STEPS, device="cpu").double().clone()], {}, None))
         record.append(("guider_scale", [sampler.guider.scale.clone()], {}, None))
+    # what the reference's `on_inference_epoch_start` does at the start of EVERY predict epoch (streaming_svd.py:46-55; its `super()` call needs the Lightning
+    # class, so the two statements are restated on the bare shell): it rebuilds the wrapper from the reference's own networks
+    def on_inference_epoch_start():
+        model.inference_model = StreamingWrapper(diffusion_model=model.model.diffusion_model, controlnet=model.controlnet,
+                                                 num_frame_conditioning=model.inference_params.num_conditional_frames)
+        model.inference_model.requires_grad_(False)
+    object.__setattr__(model, "on_inference_epoch_start", on_inference_epoch_start)
     undo = None
     if swap:
         # ------------------------------------------------------------------ INTEGRATION.md section 1, verbatim in substance --------------
@@ -149,6 +156,8 @@ def run(swap, monkeypatch=None, record=None):
         prev = ref_mod.VideoDecoder
         dropin.install(model, device="cpu", unet_cfg=ucfg, vae_cfg=VaeConfig(c["vae_ch"], c["vae_ch_mult"], c["vae_res"]))     # <- THE swap
         assert type(model.inference_model).__name__ == "HipModule" and ref_mod.VideoDecoder is dropin.VideoDecoderModule
+        model.on_inference_epoch_start()                  # trainer.predict fires it AFTER an install at the end of init_model: the swap must survive it
+        assert type(model.inference_model).__name__ == "HipModule", "on_inference_epoch_start put the reference's own wrapper back"
         undo = lambda: setattr(ref_mod, "VideoDecoder", prev)
         # ----------------------------------------------------------------------------------------------------------------------------------
     try:

@@ -624,12 +624,16 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
     if (R && (res_f32 ? ((ldr % 4) || ((uintptr_t)R & 15)) : ((ldr % 4) || ((uintptr_t)R & 7)))) return SVD_EINVAL;
     if (S && (!R || lds < FF_C || (res_f32 ? ((lds % 4) || ((uintptr_t)S & 15)) : ((lds % 4) || ((uintptr_t)S & 7))))) return SVD_EINVAL;   // blend: only with a residual
     const int ntiles = (int)((M + 127) / 128);
-    static int n_cu = 0;
+    // per-DEVICE caches (relaxed atomics: several host threads may launch; a race only repeats an idempotent query / attribute call)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SVD_ELAUNCH;
+    static int n_cu_dev[64] = {0};
+    int n_cu = __atomic_load_n(&n_cu_dev[dev], __ATOMIC_RELAXED);
     if (!n_cu) {
-        int dev = 0;
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return SVD_ELAUNCH;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return SVD_ELAUNCH;
         n_cu = p.multiProcessorCount;
+        __atomic_store_n(&n_cu_dev[dev], n_cu, __ATOMIC_RELAXED);
     }
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     const int nch = hidden / 32;
@@ -644,7 +648,8 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
         SVD_DISPATCH_DTYPE(dtype, {                                                                                                      \
             if (four_waves FF_FORCE4) {          /* probe builds: the variant alone decides */                                                                                                  \
                 auto kern = ff_geglu_fused_kernel<E, RES, OUT, BL>;                                                                       \
-                static bool attr_set = false;                                                                                            \
+                static unsigned char attr_set_dev[64] = {0};                                                                             \
+                unsigned char& attr_set = attr_set_dev[dev];                                                                             \
                 if (!attr_set) {                                                                                                         \
                     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
                     attr_set = true;                                                                                                     \
@@ -653,7 +658,8 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
                                    alpha, Y, ldy, (int)M, ntiles);                                                                                      \
             } else {                                                                                                                     \
                 auto kern = ff_geglu_fused8_kernel<E, RES, OUT, BL>;                                                                      \
-                static bool attr_set = false;                                                                                            \
+                static unsigned char attr_set_dev[64] = {0};                                                                             \
+                unsigned char& attr_set = attr_set_dev[dev];                                                                             \
                 if (!attr_set) {                                                                                                         \
                     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
                     attr_set = true;                                                                                                     \

@@ -237,8 +237,11 @@ extern "C" int svd_rowgemm320(const svd_bf16* X, int64_t ldx, const void* Wp, co
     do {                                                                                                                                  \
         SVD_DISPATCH_DTYPE(dtype, {                                                                                                       \
             auto kern = rowgemm320_kernel<E, OUTM, LNM>;                                                                                  \
-            /* idempotent and cheap: set on every call, so a second device / thread never launches without it */                           \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
+            static unsigned char attr_set_dev[64] = {0};          /* per device: the attribute belongs to the device's copy of the function */      \
+            if (!attr_set_dev[dev]) {                                                                                                      \
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
+                attr_set_dev[dev] = 1;                                                                                                    \
+            }                                                                                                                             \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RG_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const uint4*)Wp, bias, rowvec, rowvec_ld,  \
                                rows_per_vec, R, ldr, Y, ldy, ln_gamma, ln_beta, ln_eps, Yn, ldyn, (int)M, ntiles);                        \
         });                                                                                                                               \

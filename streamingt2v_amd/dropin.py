@@ -59,8 +59,20 @@ def install(model, device="cuda", unet_cfg=None, vae_cfg=None, state_dict=None, 
     cnet = ControlNet.from_unet(unet).load_state_dict(sd, device=device, prefix="controlnet.")
     dec = VideoDecoder(vae_cfg or VaeConfig()).load_state_dict(sd, device=device, prefix="first_stage_model.decoder.")
     wrapper = StreamingWrapper(diffusion_model=unet, controlnet=cnet, num_frame_conditioning=model.inference_params.num_conditional_frames)
-    model.inference_model = HipModule(wrapper)
+    shell = HipModule(wrapper)
+    model.inference_model = shell
     model.first_stage_model.decoder = VideoDecoderModule(dec)       # AutoencodingEngine.decode() keeps calling self.decoder(z, timesteps=n)
+    # The reference REBUILDS `self.inference_model = StreamingWrapper(self.model.diffusion_model, self.controlnet, ...)` at the start of every predict epoch
+    # (`on_inference_epoch_start`, streaming_svd.py:46-55) -- which would silently put its own networks back.  The hook is wrapped so that the swap is
+    # re-applied right after it, whatever the order of install() and the first trainer.predict().
+    orig_hook = getattr(model, "on_inference_epoch_start", None)
+    if callable(orig_hook) and not getattr(orig_hook, "_svdhip_reinstalls", False):
+        def on_inference_epoch_start(*args, **kwargs):
+            out = orig_hook(*args, **kwargs)
+            model.inference_model = shell
+            return out
+        on_inference_epoch_start._svdhip_reinstalls = True
+        object.__setattr__(model, "on_inference_epoch_start", on_inference_epoch_start)
     ref_module = sys.modules.get(type(model).__module__)
     if ref_module is not None and hasattr(ref_module, "VideoDecoder"):
         ref_module.VideoDecoder = VideoDecoderModule                 # the isinstance at streaming_svd.py:138
@@ -118,6 +130,18 @@ class SvdPipelineMirror:
         self.num_frames, self.device, self.conditioner = num_frames, device, conditioner
         self.svd = StreamingSVD(wrapper, first_stage_model, EulerEDMSampler(num_frames=num_frames))
 
+    # What the reference calls on the pipeline object besides __call__: `post_init` (streaming_svd.py:58-62, fired by the first trainer.predict, i.e. AFTER an
+    # install at the end of init_model) does `self.svd_pipeline.set_progress_bar_config(disable=True)` and, on a GPU, `enable_model_cpu_offload(gpu_id=...)`.
+    # Neither has anything to act on here (no progress bar; the networks stay resident in 288 GB): accepted and ignored.
+    def set_progress_bar_config(self, **kwargs):
+        return None
+
+    def enable_model_cpu_offload(self, gpu_id=None, device="cuda", **kwargs):
+        return None
+
+    def to(self, *args, **kwargs):
+        return self
+
     def __call__(self, image, height=576, width=1024, num_frames=None, num_inference_steps=25, min_guidance_scale=1.0, max_guidance_scale=3.0,
                  fps=7, motion_bucket_id=127, noise_aug_strength=0.02, decode_chunk_size=None, generator=None, output_type="pil", **_ignored):
         import types
@@ -126,8 +150,10 @@ class SvdPipelineMirror:
         import torch
         T = num_frames or self.num_frames
         assert T == self.num_frames, "the mirror was built for the pipeline's own num_frames"
-        if decode_chunk_size not in (None, 4, 8, T):
-            raise NotImplementedError("decode_chunk_size: the reference passes 8 (4 with memopt)")
+        if decode_chunk_size not in (4, 8):
+            # diffusers decodes ALL frames in one group for None / num_frames; the temporal convolutions zero-pad at group boundaries, so the grouping is part of
+            # the result -- only the two groupings the reference uses (8, or 4 with memopt: streaming_svd.py:127,388-390) are reproduced
+            raise NotImplementedError(f"decode_chunk_size={decode_chunk_size!r}: the reference passes 8 (4 with memopt); other groupings change the decoded frames")
         if isinstance(image, PIL.Image.Image):
             if image.size != (width, height):
                 image = image.resize((width, height), resample=PIL.Image.LANCZOS)          # VaeImageProcessor.preprocess(resample="lanczos")
@@ -135,8 +161,9 @@ class SvdPipelineMirror:
         img = (image.to(self.device, torch.float32) * 2.0 - 1.0).contiguous()                # [3, H, W] in [-1, 1]
         cond = self.conditioner
         cond.fps_id, cond.motion, cond.cond_aug = fps - 1, motion_bucket_id, noise_aug_strength   # "the model was trained on fps - 1"
-        aug = torch.randn((1,) + tuple(img.shape), generator=generator, device=generator.device if generator is not None else "cpu")
-        noise = torch.randn((T, 4, height // 8, width // 8), generator=generator, device=generator.device if generator is not None else "cpu")
+        rdev = generator.device if generator is not None else self.device          # diffusers draws on the execution device when no generator is given
+        aug = torch.randn((1,) + tuple(img.shape), generator=generator, device=rdev)
+        noise = torch.randn((T, 4, height // 8, width // 8), generator=generator, device=rdev)
         c, uc = cond.first_chunk(img, aug_noise=aug)
         self.svd.use_memopt = decode_chunk_size == 4
         frames = self.svd._generate_initial_chunk(c, uc, noise.to(self.device), num_steps=num_inference_steps, min_scale=min_guidance_scale,

@@ -355,8 +355,9 @@ class I2VGenXLUNet:
         """`unet.config.in_channels` / `.cross_attention_dim` / `.sample_size` as read by the pipeline (pipeline_i2vgen_xl.py:731-732,819)."""
         return self.cfg
 
-    def enable_forward_chunking(self, chunk_size=None, dim=0):
-        """Memory-only knob of the reference (unet_i2vgen_xl.py:440-470); results do not depend on it: no-op here."""
+    def enable_forward_chunking(self, dim=0, num_chunks=1, **_ignored):
+        """Memory-only knob of the reference, same signature (unet_i2vgen_xl.py:439: `(self, dim=0, num_chunks=1)`; inference_i2v.py:153 calls it with
+        `dim=0, num_chunks=4` under use_memopt); results do not depend on it: no-op here."""
         return None
 
     def eval(self):

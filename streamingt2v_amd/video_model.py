@@ -119,9 +119,13 @@ class FeedForward:
         self.w2, self.b2 = _dev_bf16(w2r, dev), _dev_f32(get(prefix + "net.2.bias"), dev)
         self.c, self.hidden = w2r.shape
         self.img = pack_ff_fused(w1r, b1r, w2r).to(dev) if ops.ff_fused_ok(self.c, self.hidden) else None
+        self.img_dtype = ops.ELEM          # the packed image is an opaque byte blob in THIS element type: the kernel must be launched with the same one
 
     def __call__(self, x, residual=None, out_f32=False, blend=None):
         if self.img is not None and ops.FF_FUSED:
+            if x.dtype != self.img_dtype:
+                raise TypeError(f"fused feed-forward weights were packed as {self.img_dtype} (ops.ELEM at load_state_dict) but the activations are {x.dtype}: "
+                                f"call ops.set_element_dtype BEFORE load_state_dict")
             return ops.ff_geglu_fused(x, self.img, self.hidden, self.b2, residual=residual, blend=blend, out_f32=out_f32)
         g = ops.gemm(x, self.w1, bias=self.b1, geglu=True)
         return ops.gemm(g, self.w2, bias=self.b2, residual=residual, blend=blend, out_f32=out_f32)
@@ -342,7 +346,7 @@ class SpatialVideoTransformer:
         self.rg = None
         if self.c == 320:
             R = lambda k: pack_rowgemm320(g(k)).to(dev)
-            self.rg = dict(pi=R("proj_in.weight"), so=R(b + "attn1.to_out.0.weight"), to=R(t + "attn1.to_out.0.weight"))
+            self.rg = dict(pi=R("proj_in.weight"), so=R(b + "attn1.to_out.0.weight"), to=R(t + "attn1.to_out.0.weight"), dtype=ops.ELEM)
         self.tp_w0, self.tp_b0 = W("time_pos_embed.0.weight"), Fv("time_pos_embed.0.bias")
         self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))
@@ -428,7 +432,7 @@ class SpatialVideoTransformer:
         h = ops.groupnorm(x, F, pix, self.nw, self.nb, 1e-6, silu=False)
         # round 6: with the fp32 stream on, a 320-channel block's proj_in / to_out / proj_out run in the row-owning kernel, which also emits the LayerNorm
         # of its result (norm1 / norm3) -- one launch instead of svd_gemm + svd_layernorm, the fp32 tensor is not read back
-        rg = self.rg if (st and self.rg is not None and x.dtype == torch.float32 and ops.rowgemm_ok(h, self.rg["pi"], pix)) else None
+        rg = self.rg if (st and self.rg is not None and x.dtype == torch.float32 and h.dtype == self.rg["dtype"] and ops.rowgemm_ok(h, self.rg["pi"], pix)) else None
         # ---- spatial BasicTransformerBlock (attention.py:567-593) ----
         if rg is not None:
             h, n1 = ops.rowgemm320(h, rg["pi"], bias=self.bpi, ln=self.s_ln["norm1"])

@@ -45,3 +45,24 @@ def test_hot_path_objects_are_registered_modules_so_the_swap_needs_the_module_sh
     assert isinstance(host.decoder, HipModule) and host.decoder.marker == 7
     assert torch.equal(host.decoder(torch.ones(2), k=3), torch.full((2,), 3.0))
     assert len(list(host.parameters())) == 0 and host.decoder.to("cpu") is host.decoder
+
+
+def test_svd_pipeline_mirror_accepts_the_calls_post_init_makes_and_refuses_other_decode_groupings():
+    """streaming_svd.py:58-62 (`post_init`, fired by the first trainer.predict -- after an install at the end of init_model) calls
+    `svd_pipeline.set_progress_bar_config(disable=True)` and `.enable_model_cpu_offload(gpu_id=...)` on whatever sits in `self.svd_pipeline`."""
+    from streamingt2v_amd.dropin import SvdPipelineMirror
+    m = SvdPipelineMirror.__new__(SvdPipelineMirror)          # the hooks need no networks
+    assert m.set_progress_bar_config(disable=True) is None and m.enable_model_cpu_offload(gpu_id=0) is None and m.to("cuda") is m
+    m.num_frames, m.device = 25, "cpu"
+    for bad in (None, 25, 2):
+        with pytest.raises(NotImplementedError):
+            m(torch.zeros(3, 16, 16), height=16, width=16, decode_chunk_size=bad)
+
+
+def test_enhancer_mirror_takes_the_memopt_chunking_call():
+    """inference_i2v.py:153: `enhance_pipeline.unet.enable_forward_chunking(dim=0, num_chunks=4)` (reference signature unet_i2vgen_xl.py:439)."""
+    import inspect
+    from streamingt2v_amd.i2vgen_unet import I2VGenXLUNet
+    sig = inspect.signature(I2VGenXLUNet.enable_forward_chunking)
+    assert list(sig.parameters)[:3] == ["self", "dim", "num_chunks"]
+    assert I2VGenXLUNet.enable_forward_chunking(object(), dim=0, num_chunks=4) is None
