@@ -13,10 +13,10 @@
 // of gemm_impl.inc moves them at 2.7 TB/s (profiles/r05_roofline_table.txt: cfg 21 view 0), and its epilogue cannot normalise a row because a row's
 // 320 outputs are spread over the lanes of two waves.  Here, as in ff_fused.hip, one WAVE owns 32 token rows and ALL 320 outputs of those rows:
 //
-//   * O^T[channel, row] = W . X^T on v_mfma_f32_32x32x16: a lane holds ITS row's outputs (160 accumulator registers, the other 160 in lane ^ 32), so
-//     bias, residual, LayerNorm statistics (one cross-half exchange), affine and the 16-bit pack are lane-local;
-//   * the accumulators START as the residual rows: the 40 float4 loads of R land directly in the accumulator registers (one burst of 40 KiB per wave,
-//     no staging registers), the products are added on top (fp32 sum in a different order than `gemm` + residual: equal to ~1e-7 relative);
+//   * V[row, channel] = X . W^T on v_mfma_f32_32x32x16: the wave's 64 lanes hold the complete 32 x 320 block (160 accumulator registers per lane), so bias,
+//     residual, LayerNorm (a 32-lane butterfly per token), affine and the 16-bit rounding need nothing from another wave (layout: at the kernel);
+//   * the accumulators START as the residual rows: the 160 dword loads of R land directly in the accumulator registers (no staging registers),
+//     the products are added on top (fp32 sum in a different order than `gemm` + residual: equal to ~1e-7 relative);
 //   * the waves are INDEPENDENT: no barrier, no LDS ring, no DMA bookkeeping inside the tile loop.  Three quarters of W (the fragments of k-steps 5..19,
 //     150 KiB) are copied to LDS once per workgroup and only read afterwards; the fragments of k-steps 0..4 (50 KiB) stream from L2 through a register
 //     ring at the head of every tile -- all of W does not fit 160 KiB, and the ring's loads sit in the shadow of the residual burst;
@@ -33,12 +33,18 @@ constexpr int RG_NO = RG_C / 32;                  // 10 output tiles of 32 chann
 constexpr int RG_NF = RG_NS * RG_NO;              // 200 W fragments of 1 KiB (fragment i = s * 10 + o)
 constexpr int RG_GS = 5;                          // k-steps whose fragments stream from L2 (fragments 0 .. 49)
 constexpr int RG_GF = RG_GS * RG_NO;              // 50
-constexpr int RG_RING = 20;                       // register ring of global fragments: two k-steps ahead
+constexpr int RG_RING = 10;                       // register ring of global fragments: one k-step ahead
 constexpr int RG_LDS_W = (RG_NF - RG_GF) * 1024;  // 153 600 B of fragments resident in LDS
-constexpr int RG_LDS_G = RG_LDS_W;                // gamma | beta | bias: 3 x 1 280 B
-constexpr int RG_LDS_TOTAL = RG_LDS_W + 3 * RG_C * 4;          // 157 440 B
+constexpr int RG_LDS_TOTAL = RG_LDS_W;            // 150 KiB: one workgroup (4 waves) per CU
 
 // OUT: 0 = no Y, 1 = fp32 rows, 2 = 16-bit rows.  LN: also write Yn = LayerNorm(V).  R, rowvec: run-time (wave-uniform) options.
+//
+// Register layout (round 6, second form).  D[token, channel] = X . W^T with X as the A operand: accumulator register r of output tile o in lane (l31, hi) is
+// token (r & 3) + 8 (r >> 2) + 4 hi, channel 32 o + l31 -- a LANE IS A CHANNEL.  One dword load / store per register then moves 2 token rows x 128 contiguous
+// bytes per instruction: tools/access_pattern_bench.hip measures this pattern at 5.3 TB/s with FOUR waves per CU (this kernel's occupancy: LDS holds W) against
+// 2.7 TB/s for the transposed layout's "lane = token row, 16 B per lane" (32 rows x 32 B per instruction), which the first form of this kernel used (3.9 TB/s in
+// the kernel, profiles/r06_rowgemm_probe.txt) -- the memory pipeline pays per cache line an instruction touches, not per byte.  The LayerNorm statistics become a
+// 32-lane butterfly per token (16 tokens per half-wave: 160 shuffles per tile), cheap next to the 480 KiB a CU moves per round.
 template <class E, int OUT, bool LN>
 __global__ __launch_bounds__(256, 1) void rowgemm320_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const uint4* __restrict__ Wp,
                                                             const float* __restrict__ bias, const float* __restrict__ rowvec, int rowvec_ld,
@@ -50,64 +56,70 @@ __global__ __launch_bounds__(256, 1) void rowgemm320_kernel(const svd_bf16* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // ---- once per workgroup: the resident part of W and the per-channel vectors -> LDS
+    // ---- once per workgroup: the resident part of W -> LDS (loads in batches of 8 so that the copy is not one L2 round trip per 16 bytes)
     {
         uint4* wl = (uint4*)smem;
         const uint4* src = Wp + RG_GF * 64;
-        for (int i = tid; i < (RG_NF - RG_GF) * 64; i += 256) wl[i] = src[i];
-        float* vec = (float*)(smem + RG_LDS_G);
-        for (int i = tid; i < RG_C; i += 256) {
-            vec[i] = LN ? gamma[i] : 0.f;
-            vec[RG_C + i] = LN ? beta[i] : 0.f;
-            vec[2 * RG_C + i] = bias ? bias[i] : 0.f;
+        constexpr int N16 = (RG_NF - RG_GF) * 64;                       // 9 600 uint4
+        for (int i0 = tid; i0 < N16; i0 += 256 * 8) {
+            uint4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + 256 * k; t[k] = src[i < N16 ? i : N16 - 1]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + 256 * k; if (i < N16) wl[i] = t[k]; }
         }
     }
     __syncthreads();
+    // per-channel vectors of THIS lane's 10 channels (32 o + l31): loaded once, 30 registers
+    float gam[RG_NO], bet[RG_NO], bia[RG_NO];
+#pragma unroll
+    for (int o = 0; o < RG_NO; ++o) {
+        gam[o] = LN ? gamma[32 * o + l31] : 0.f;
+        bet[o] = LN ? beta[32 * o + l31] : 0.f;
+        bia[o] = bias ? bias[32 * o + l31] : 0.f;
+    }
     const char* wfrag0 = smem + lane * 16;                             // LDS fragment i (i >= 50) at wfrag + (i - 50) KiB
-    const float* gam0 = (const float*)(smem + RG_LDS_G) + 4 * hi;      // this half's 4-channel groups: + 32 o + 8 j
     const uint4* wg0 = Wp + lane;                                      // global fragment i (i < 50) at wg[64 i]
 
     const int nw = (int)gridDim.x * 4;
     for (int tile = (int)blockIdx.x * 4 + wave; tile < ntiles; tile += nw) {
-        const int row = tile * 32 + l31;
-        const int rowc = row < M ? row : M - 1;                        // tail: the lanes past M recompute row M - 1 from the same inputs and store the SAME bytes to it
-                                                                       // (benign duplicate stores: no exec-mask branch around each of the 60 stores)
-        // W, gamma, beta and bias are the same for every tile: made opaque per iteration, or the compiler hoists their ~300 registers of loads out of
-        // the tile loop and spills them (ISA audit of the first build: 80 spilled VGPRs, all of them hoisted ring / vector loads)
-        // (an opaque ZERO OFFSET, not an opaque pointer: a pointer that went through an asm operand loses its address space and every LDS / global
-        //  access through it becomes a flat_load, which counts on lgkmcnt AND vmcnt and forces vmcnt(0) waits)
+        const int row0 = tile * 32;
+        // W is the same for every tile: an opaque ZERO OFFSET per iteration keeps the compiler from hoisting the ring's loads out of the tile loop (the first
+        // build spilled 80 registers of hoisted loads); an opaque POINTER would lose its address space and turn every access into a flat_load
         int zero;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
         const char* wfrag = wfrag0 + zero;
-        const float* gam = gam0 + zero;
         const uint4* wg = wg0 + zero;
-        // ---- the tile's loads, one burst: the per-frame vector (consumed first: oldest in the in-order queue), residual rows straight into the
-        //      accumulators, the X fragments, the first two k-steps of W
+        // token rows of this lane's 16 accumulator registers, clamped at the tail: the lanes / registers past M recompute row M - 1 from the same inputs and
+        // store the SAME bytes to it (benign duplicate stores, no exec-mask branch around each of the ~500 memory instructions)
+        int trow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int t = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi; trow[r] = t < M ? t : M - 1; }
+        const int xrow = row0 + l31 < M ? row0 + l31 : M - 1;
+        // ---- the tile's loads, one burst: per-frame vector (consumed first), residual rows straight into the accumulators, X fragments, first k-steps of W
         float vec[RG_NO];
         {
-            const float* rvp = rowvec ? rowvec + (int64_t)((tile * 32) / rows_per_vec) * rowvec_ld + l31 : nullptr;   // rows_per_vec % 32 == 0: one vector per tile
+            const float* rvp = rowvec ? rowvec + (int64_t)(row0 / rows_per_vec) * rowvec_ld + l31 : nullptr;          // rows_per_vec % 32 == 0: one vector per tile
 #pragma unroll
             for (int o = 0; o < RG_NO; ++o) vec[o] = rvp ? rvp[32 * o] : 0.f;
         }
         f32x16_t acc[RG_NO];
         if (R) {
-            const float* rp = R + (int64_t)rowc * ldr + 4 * hi;
 #pragma unroll
-            for (int o = 0; o < RG_NO; ++o)
+            for (int r = 0; r < 16; ++r) {
+                const float* rp = R + (int64_t)trow[r] * ldr + l31;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 r = *(const float4*)(rp + 32 * o + 8 * j);
-                    acc[o][4 * j + 0] = r.x; acc[o][4 * j + 1] = r.y; acc[o][4 * j + 2] = r.z; acc[o][4 * j + 3] = r.w;
-                }
+                for (int o = 0; o < RG_NO; ++o) acc[o][r] = rp[32 * o];
+            }
         } else {
 #pragma unroll
             for (int o = 0; o < RG_NO; ++o)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[o][i] = 0.f;
         }
-        uint4 xf[RG_NS];                                               // lane (row l31, half hi): channels 16 s + 8 hi .. + 7 of k-step s (B operand)
+        uint4 xf[RG_NS];                                               // A operand: lane (token l31, half hi) holds channels 16 s + 8 hi .. + 7 of k-step s
         {
-            const svd_bf16* xp = X + (int64_t)rowc * ldx + 8 * hi;
+            const svd_bf16* xp = X + (int64_t)xrow * ldx + 8 * hi;
 #pragma unroll
             for (int s = 0; s < RG_NS; ++s) xf[s] = *(const uint4*)(xp + 16 * s);
         }
@@ -115,90 +127,79 @@ __global__ __launch_bounds__(256, 1) void rowgemm320_kernel(const svd_bf16* __re
 #pragma unroll
         for (int i = 0; i < RG_RING; ++i) gr[i] = wg[64 * i];
         __builtin_amdgcn_sched_barrier(0);
-        // bias + per-frame vector enter through the matrix pipe as well: one extra k-step whose A operand holds the vector split into two 16-bit
-        // values (hi + lo: ~22 bits in fp16) and whose B operand is 1 -- 10 coalesced dword loads per tile instead of 40 strided float4 loads, and no
-        // load in the epilogue at all (a load behind the epilogue's stores would wait for every one of them: vmcnt is in order)
+        // bias + per-frame vector enter through the matrix pipe: one extra k-step whose A operand is 1 (k = 0, 1) and whose B operand holds the vector split into two
+        // 16-bit values (hi + lo: ~22 bits in fp16) -- 10 coalesced dword loads per tile, no VALU pass over the 160 accumulators, no load in the epilogue
         {
-            const float* bl = gam - 4 * hi + 2 * RG_C + l31;
             uint4 ones = {0u, 0u, 0u, 0u};
             if (hi == 0) ones.x = E::pack(1.f, 1.f);
 #pragma unroll
             for (int o = 0; o < RG_NO; ++o) {
-                const float v = vec[o] + bl[32 * o];
+                const float v = vec[o] + bia[o];
                 const float vh = E::lo(E::pack(v, 0.f));
-                uint4 av = {0u, 0u, 0u, 0u};
-                if (hi == 0) av.x = E::pack(vh, v - vh);
-                acc[o] = E::mfma(av, ones, acc[o]);
+                uint4 bv = {0u, 0u, 0u, 0u};
+                if (hi == 0) bv.x = E::pack(vh, v - vh);
+                acc[o] = E::mfma(ones, bv, acc[o]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- 200 MFMAs: k-step outer, output tile inner; fragment i = 10 s + o from the register ring (i < 50) or from LDS three reads ahead
+        // ---- 200 MFMAs: k-step outer, output tile inner; W fragment i = 10 s + o (B operand) from the register ring (i < 50) or from LDS three reads ahead
         uint4 lr[4];
 #pragma unroll
         for (int i = 0; i < RG_NF; ++i) {
             const int s = i / RG_NO, o = i % RG_NO;
             if (i + 3 >= RG_GF && i + 3 < RG_NF) lr[(i + 3) & 3] = *(const uint4*)(wfrag + (i + 3 - RG_GF) * 1024);
             if (i < RG_GF) {
-                acc[o] = E::mfma(gr[i % RG_RING], xf[s], acc[o]);
+                acc[o] = E::mfma(xf[s], gr[i % RG_RING], acc[o]);
                 if (i + RG_RING < RG_GF) gr[i % RG_RING] = wg[64 * (i + RG_RING)];
             } else {
-                acc[o] = E::mfma(lr[i & 3], xf[s], acc[o]);
+                acc[o] = E::mfma(xf[s], lr[i & 3], acc[o]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- epilogue: lane holds row l31, channels 32 o + 8 j + 4 hi .. + 3 in acc[o][4 j .. 4 j + 3]
-        float sum = 0.f;
+        // ---- epilogue: acc[o][r] = V[token trow[r]][channel 32 o + l31]
+        if constexpr (OUT == 1) {
 #pragma unroll
-        for (int o = 0; o < RG_NO; ++o)
+            for (int r = 0; r < 16; ++r) {
+                float* yp = (float*)Y + (int64_t)trow[r] * ldy + l31;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 v = {acc[o][4 * j], acc[o][4 * j + 1], acc[o][4 * j + 2], acc[o][4 * j + 3]};
-                if constexpr (LN) sum += (v.x + v.y) + (v.z + v.w);
-                if constexpr (OUT == 1) {
-                    *(float4*)((float*)Y + (int64_t)rowc * ldy + 32 * o + 8 * j + 4 * hi) = v;
-                }
+                for (int o = 0; o < RG_NO; ++o) yp[32 * o] = acc[o][r];
             }
+        }
         if constexpr (OUT == 2) {
-            // 16-bit rows: a lane's 4 channels of group j and its partner's (lane ^ 32) are 8 consecutive channels -> one 16-byte store per PAIR of groups
-            // (v_permlane32_swap: lower half keeps group j and receives the upper half's group j; upper half receives the lower half's group j + 1)
 #pragma unroll
-            for (int o = 0; o < RG_NO; ++o)
+            for (int r = 0; r < 16; ++r) {
+                svd_bf16* yp = (svd_bf16*)Y + (int64_t)trow[r] * ldy + l31;
 #pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    uint32_t a0 = E::pack(acc[o][4 * j], acc[o][4 * j + 1]), a1 = E::pack(acc[o][4 * j + 2], acc[o][4 * j + 3]);
-                    uint32_t b0 = E::pack(acc[o][4 * j + 4], acc[o][4 * j + 5]), b1 = E::pack(acc[o][4 * j + 6], acc[o][4 * j + 7]);
-                    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                    uint4 w; w.x = r0[0]; w.y = r1[0]; w.z = r0[1]; w.w = r1[1];
-                    *(uint4*)((svd_bf16*)Y + (int64_t)rowc * ldy + 32 * o + 8 * j + 8 * hi) = w;
-                }
+                for (int o = 0; o < RG_NO; ++o) yp[32 * o] = E::from_f32(acc[o][r]);
+            }
         }
         if constexpr (LN) {
             constexpr float invc = 1.f / (float)RG_C;
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * invc;
-            float sq = 0.f;
+            float mean[16], rstd[16];
 #pragma unroll
-            for (int o = 0; o < RG_NO; ++o)
+            for (int r = 0; r < 16; ++r) {
+                float sm = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { const float d = acc[o][i] - mean; sq += d * d; }
-            sq += __shfl_xor(sq, 32, 64);
-            const float rstd = rsqrtf(sq * invc + eps);
+                for (int o = 0; o < RG_NO; ++o) sm += acc[o][r];
 #pragma unroll
-            for (int o = 0; o < RG_NO; ++o)
+                for (int m = 1; m < 32; m <<= 1) sm += __shfl_xor(sm, m, 64);        // the 32 lanes of a half-wave hold the same 16 tokens
+                mean[r] = sm * invc;
+            }
 #pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    const float4 g0 = *(const float4*)(gam + 32 * o + 8 * j), g1 = *(const float4*)(gam + 32 * o + 8 * j + 8);
-                    const float4 e0 = *(const float4*)(gam + RG_C + 32 * o + 8 * j), e1 = *(const float4*)(gam + RG_C + 32 * o + 8 * j + 8);
-                    const float y0 = (acc[o][4 * j] - mean) * rstd * g0.x + e0.x, y1 = (acc[o][4 * j + 1] - mean) * rstd * g0.y + e0.y;
-                    const float y2 = (acc[o][4 * j + 2] - mean) * rstd * g0.z + e0.z, y3 = (acc[o][4 * j + 3] - mean) * rstd * g0.w + e0.w;
-                    const float y4 = (acc[o][4 * j + 4] - mean) * rstd * g1.x + e1.x, y5 = (acc[o][4 * j + 5] - mean) * rstd * g1.y + e1.y;
-                    const float y6 = (acc[o][4 * j + 6] - mean) * rstd * g1.z + e1.z, y7 = (acc[o][4 * j + 7] - mean) * rstd * g1.w + e1.w;
-                    const auto r0 = __builtin_amdgcn_permlane32_swap(E::pack(y0, y1), E::pack(y4, y5), false, false);
-                    const auto r1 = __builtin_amdgcn_permlane32_swap(E::pack(y2, y3), E::pack(y6, y7), false, false);
-                    uint4 w; w.x = r0[0]; w.y = r1[0]; w.z = r0[1]; w.w = r1[1];
-                    *(uint4*)(Yn + (int64_t)rowc * ldyn + 32 * o + 8 * j + 8 * hi) = w;
-                }
+            for (int r = 0; r < 16; ++r) {
+                float sq = 0.f;
+#pragma unroll
+                for (int o = 0; o < RG_NO; ++o) { const float d = acc[o][r] - mean[r]; sq += d * d; }
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) sq += __shfl_xor(sq, m, 64);
+                rstd[r] = rsqrtf(sq * invc + eps);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                svd_bf16* np = Yn + (int64_t)trow[r] * ldyn + l31;
+#pragma unroll
+                for (int o = 0; o < RG_NO; ++o) np[32 * o] = E::from_f32((acc[o][r] - mean[r]) * rstd[r] * gam[o] + bet[o]);
+            }
         }
     }
 }

@@ -406,6 +406,7 @@ def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=Fal
 # LayerNorm that follows (norm1 / norm3): a wave owns 32 token rows and all 320 outputs, the fp32 tensor the projection writes is not read back by a norm
 # kernel.  SVD_ROWGEMM=0 keeps svd_gemm + svd_layernorm (A/B).
 ROWGEMM = _os.environ.get("SVD_ROWGEMM", "1") != "0"
+ROWGEMM_PLAIN_MIN_ROWS = int(_os.environ.get("SVD_ROWGEMM_PLAIN_MIN_ROWS", "200000"))     # projections WITHOUT a fused LayerNorm: rowgemm320 from this many rows on
 
 
 def rowgemm_ok(x, w_img, rows_per_vec=0):

@@ -346,7 +346,7 @@ class SpatialVideoTransformer:
         self.rg = None
         if self.c == 320:
             R = lambda k: pack_rowgemm320(g(k)).to(dev)
-            self.rg = dict(pi=R("proj_in.weight"), so=R(b + "attn1.to_out.0.weight"), to=R(t + "attn1.to_out.0.weight"), dtype=ops.ELEM)
+            self.rg = dict(pi=R("proj_in.weight"), so=R(b + "attn1.to_out.0.weight"), to=R(t + "attn1.to_out.0.weight"), po=R("proj_out.weight"), dtype=ops.ELEM)
         self.tp_w0, self.tp_b0 = W("time_pos_embed.0.weight"), Fv("time_pos_embed.0.bias")
         self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))
@@ -492,8 +492,10 @@ class SpatialVideoTransformer:
             xb = sp.to_frames(xb, B, T, pix)                                                    # one all-to-all out
         # xb (the blend) is consumed by proj_out only: a GEMM operand, 16 bit; proj_out + x continues the stream
         out32 = st or (ops.STREAM_F32_SVT_IO_MIN_CH > 0 and c >= ops.STREAM_F32_SVT_IO_MIN_CH)      # (A/B) block output alone in fp32
-        # (proj_out has no LayerNorm behind it: without the fusion the row-owning kernel is no faster than the 256 x 320 tile -- 342 vs 330 us at M = 460 800,
-        #  profiles/r06_rowgemm_probe.txt -- so it stays on svd_gemm)
+        # proj_out has no LayerNorm behind it; the row-owning kernel still moves its rows faster than the 256 x 320 tile on the large token matrices
+        # (307 vs 353 us at M = 460 800, 667 vs 781 us at 1 094 400; 111 vs 107 us at 129 024: profiles/r06_rowgemm_probe_v2.txt)
+        if rg is not None and M >= ops.ROWGEMM_PLAIN_MIN_ROWS:
+            return ops.rowgemm320(xb, rg["po"], bias=self.bpo, residual=x)[0]
         return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out_f32=out32)
 
 

@@ -409,6 +409,8 @@ def install(monkeypatch=None):
         else:
             setattr(ops, n, fn)
     if monkeypatch is not None:
+        monkeypatch.setattr(ops, "ROWGEMM_PLAIN_MIN_ROWS", 0, raising=False)          # host-logic tests: every rowgemm320 call site, whatever the row count
         monkeypatch.setattr(ops, "ELEM", torch.float32)
     else:
+        ops.ROWGEMM_PLAIN_MIN_ROWS = 0
         ops.ELEM = torch.float32
