@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from .params import Spec, check_state_dict
-from .video_model import FeedForward, _dev_bf16, _dev_f32, _gn_pooled, _spec_ln, pack_conv3x3, pack_tconv3, pack_x3, pad_rows
+from .video_model import FeedForward, RowProj, _dev_bf16, _dev_f32, _gn_pooled, _spec_ln, pack_conv3x3, pack_tconv3, pack_x3, pad_rows
 
 
 def _pad32(c):
@@ -170,14 +170,17 @@ class _Transformer2D:
         W, Fv = (lambda k: _dev_bf16(g(k), dev)), (lambda k: _dev_f32(g(k), dev))
         self.dev = dev
         self.n = (Fv("norm.weight"), Fv("norm.bias"))
-        self.wpi, self.bpi, self.wpo, self.bpo = W("proj_in.weight"), Fv("proj_in.bias"), W("proj_out.weight"), Fv("proj_out.bias")
+        self.bpi, self.bpo = Fv("proj_in.bias"), Fv("proj_out.bias")
         b = "transformer_blocks.0."
         self.ln = {n: (Fv(b + n + ".weight"), Fv(b + n + ".bias")) for n in ("norm1", "norm2", "norm3")}
         self.wqk = _dev_bf16(torch.cat([g(b + "attn1.to_q.weight"), g(b + "attn1.to_k.weight")], 0), dev)
-        self.wv, self.wo, self.bo = W(b + "attn1.to_v.weight"), W(b + "attn1.to_out.0.weight"), Fv(b + "attn1.to_out.0.bias")
+        self.wv, self.bo = W(b + "attn1.to_v.weight"), Fv(b + "attn1.to_out.0.bias")
         self.wq2, self.wk2, self.wv2 = W(b + "attn2.to_q.weight"), W(b + "attn2.to_k.weight"), W(b + "attn2.to_v.weight")
-        self.wo2, self.bo2 = W(b + "attn2.to_out.0.weight"), Fv(b + "attn2.to_out.0.bias")
+        self.bo2 = Fv(b + "attn2.to_out.0.bias")
         self.ff = FeedForward(g, b + "ff.", dev)
+        # round 6: the block's four C -> C projections with the LayerNorm behind them (ops.rowgemm320 at C = 320, else svd_gemm + svd_layernorm)
+        self.p_in, self.p_o1, self.p_o2, self.p_out = (RowProj(g(k), dev) for k in ("proj_in.weight", b + "attn1.to_out.0.weight", b + "attn2.to_out.0.weight",
+                                                                                    "proj_out.weight"))
 
     def set_context(self, ctx_tok, ctx_pad_tok, B, n_ctx, n_pad):
         """K and V^T of the cross-attention depend only on the context: once per chunk (attention.py:488-501).
@@ -201,20 +204,19 @@ class _Transformer2D:
         c, pix, M = self.c, H * W, F * H * W
         st = ops.i2v_stream_on(c)               # fp32 residual stream: h and the block output are fp32 between the kernels; every GEMM / attention operand is 16 bit
         e16 = ops.ELEM if x.dtype == torch.float32 else x.dtype
-        h = ops.gemm(ops.groupnorm(x, F, pix, *self.n, 1e-6), self.wpi, bias=self.bpi, out_f32=st)
-        n1 = ops.layernorm(h, *self.ln["norm1"])
+        h, n1 = self.p_in(ops.groupnorm(x, F, pix, *self.n, 1e-6), bias=self.bpi, ln=self.ln["norm1"], stream=st)
         qk = ops.gemm(n1, self.wqk)
         vt, tok_ld = self._vt_buf(F, pix, e16)
         ops.gemm(n1, self.wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
         a = torch.empty((M, c), dtype=e16, device=x.device)
         ops.attn_spatial(qk[:, :c], qk[:, c:], vt, a, F, pix, self.heads)
-        h = ops.gemm(a, self.wo, bias=self.bo, residual=h, out_f32=st)
+        h, n2 = self.p_o1(a, bias=self.bo, residual=h, ln=self.ln["norm2"], stream=st)
         k2, vt2, n_ctx = self.kv
-        q2 = ops.gemm(ops.layernorm(h, *self.ln["norm2"]), self.wq2)
+        q2 = ops.gemm(n2, self.wq2)
         ops.attn_cross(q2, k2, vt2, a, F, pix, n_ctx, Fr, self.heads)
-        h = ops.gemm(a, self.wo2, bias=self.bo2, residual=h, out_f32=st)
-        h = self.ff(ops.layernorm(h, *self.ln["norm3"]), residual=h)          # x + ff(x) is consumed by proj_out only: a GEMM operand, 16 bit
-        return ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
+        h, n3 = self.p_o2(a, bias=self.bo2, residual=h, ln=self.ln["norm3"], stream=st)
+        h = self.ff(n3, residual=h)                                           # x + ff(x) is consumed by proj_out only: a GEMM operand, 16 bit
+        return self.p_out(h, bias=self.bpo, residual=x, stream=st)[0]
 
 
 class _TransformerTemporal:
@@ -234,14 +236,15 @@ class _TransformerTemporal:
         g = lambda k: sd[self.p + k]
         W, Fv = (lambda k: _dev_bf16(g(k), dev)), (lambda k: _dev_f32(g(k), dev))
         self.n = (Fv("norm.weight"), Fv("norm.bias"))
-        self.wpi, self.bpi, self.wpo, self.bpo = W("proj_in.weight"), Fv("proj_in.bias"), W("proj_out.weight"), Fv("proj_out.bias")
+        self.bpi, self.bpo = Fv("proj_in.bias"), Fv("proj_out.bias")
         b = "transformer_blocks.0."
         self.ln = {n: (Fv(b + n + ".weight"), Fv(b + n + ".bias")) for n in ("norm1", "norm2", "norm3")}
         cat3 = lambda a: _dev_bf16(torch.cat([g(b + a + ".to_q.weight"), g(b + a + ".to_k.weight"), g(b + a + ".to_v.weight")], 0), dev)
         self.wqkv1, self.wqkv2 = cat3("attn1"), cat3("attn2")
-        self.wo1, self.bo1 = W(b + "attn1.to_out.0.weight"), Fv(b + "attn1.to_out.0.bias")
-        self.wo2, self.bo2 = W(b + "attn2.to_out.0.weight"), Fv(b + "attn2.to_out.0.bias")
+        self.bo1, self.bo2 = Fv(b + "attn1.to_out.0.bias"), Fv(b + "attn2.to_out.0.bias")
         self.ff = FeedForward(g, b + "ff.", dev)
+        self.p_in, self.p_o1, self.p_o2, self.p_out = (RowProj(g(k), dev) for k in ("proj_in.weight", b + "attn1.to_out.0.weight", b + "attn2.to_out.0.weight",
+                                                                                    "proj_out.weight"))
 
     def forward(self, x, F, Fr, H, W, sp=None):
         """sp (parallel.SeqParallel): the frame <-> pixel split of TransformerTemporalModel (transformer_temporal.py:121-200): the whole block is
@@ -258,14 +261,14 @@ class _TransformerTemporal:
             x = sp.to_pixels(x, B, Fr, pix)
             hn = _gn_pooled(x, B * Fr, pix_l, *self.n, 1e-6, Fr, float(Fr) * pix * (self.c // 32), sp, False)
         M = B * Fr * pix_l
-        h = ops.gemm(hn, self.wpi, bias=self.bpi, out_f32=st)
+        h, n = self.p_in(hn, bias=self.bpi, ln=self.ln["norm1"], stream=st)
         a = torch.empty((M, d), dtype=e16, device=x.device)
-        for ln, wqkv, wo, bo in (("norm1", self.wqkv1, self.wo1, self.bo1), ("norm2", self.wqkv2, self.wo2, self.bo2)):
-            qkv = ops.gemm(ops.layernorm(h, *self.ln[ln]), wqkv)
+        for nxt, wqkv, po, bo in (("norm2", self.wqkv1, self.p_o1, self.bo1), ("norm3", self.wqkv2, self.p_o2, self.bo2)):
+            qkv = ops.gemm(n, wqkv)
             ops.attn_temporal(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, B, Fr, Fr, pix_l, self.heads)
-            h = ops.gemm(a, wo, bias=bo, residual=h, out_f32=st)
-        h = self.ff(ops.layernorm(h, *self.ln["norm3"]), residual=h)          # consumed by proj_out only: 16 bit
-        out = ops.gemm(h, self.wpo, bias=self.bpo, residual=x, out_f32=st)
+            h, n = po(a, bias=bo, residual=h, ln=self.ln[nxt], stream=st)      # ... and the LayerNorm the NEXT sub-block reads
+        h = self.ff(n, residual=h)                                            # consumed by proj_out only: 16 bit
+        out = self.p_out(h, bias=self.bpo, residual=x, stream=st)[0]
         return out if sp is None else sp.to_frames(out, B, Fr, pix)
 
 

@@ -106,6 +106,25 @@ def pack_rowgemm320(w):
     return img.view(-1).view(torch.uint8)
 
 
+class RowProj:
+    """A 320 -> 320 projection of the fp32 residual stream, optionally with the LayerNorm that consumes its result: ONE launch of svd_rowgemm320 where that
+    kernel applies (dim 320, fp32 stream, the per-frame vector constant inside a 32-row tile), else svd_gemm (+ svd_layernorm).
+    __call__(x16, bias=, rowvec=, rows_per_vec=, residual=, ln=(gamma, beta), stream=) -> (y, LayerNorm(y) or None)."""
+
+    def __init__(self, w, dev):
+        self.w = _dev_bf16(w, dev)
+        self.img = pack_rowgemm320(w).to(dev) if tuple(w.shape) == (320, 320) else None
+        self.dtype = ops.ELEM
+
+    def __call__(self, x, bias=None, rowvec=None, rows_per_vec=0, residual=None, ln=None, stream=True):
+        fused = (stream and self.img is not None and x.dtype == self.dtype and (residual is None or residual.dtype == torch.float32)
+                 and ops.rowgemm_ok(x, self.img, rows_per_vec) and (ln is not None or x.shape[0] >= ops.ROWGEMM_PLAIN_MIN_ROWS))
+        if fused:
+            return ops.rowgemm320(x, self.img, bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, residual=residual, ln=ln)
+        y = ops.gemm(x, self.w, bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, residual=residual, out_f32=stream)
+        return y, (ops.layernorm(y, *ln) if ln is not None else None)
+
+
 class FeedForward:
     """FeedForward(dim, mult 4, glu=True) = GEGLU.proj -> value * gelu(gate) -> net[2] (attention.py:94-120; diffusers FeedForward "geglu" in the
     enhancer) on the kernel path: ONE launch of svd_ff_geglu_fused where the fused kernel exists (dim 320: the level-0 blocks, whose [M, 1280]

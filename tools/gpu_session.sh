@@ -82,6 +82,10 @@ for step in "$@"; do
               grep -E "^\[|passed|failed|FAILED" $O/gpu_tests_full.log | grep -v "Gloo\|W924\|c10d" > $O/gpu_test_lines.txt; tail -1 $O/gpu_test_lines.txt; grep -A42 "slowest 40 durations" $O/gpu_tests_full.log > $O/gpu_test_durations.txt; head -14 $O/gpu_test_durations.txt
               (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -i "smoke") > $O/smoke.txt; cat $O/smoke.txt ;;
     pmc)      bash tools/pmc_round4.sh $O ;;
+    pmc6)     bash tools/pmc_round6.sh $O ;;
+    i2vtests) timeout 900 python -m pytest tests/test_gpu_i2v.py tests/test_gpu_fullsize_parity.py -m gpu -q -x -s -p no:cacheprovider -k "i2v or enhancer or shipped_architecture" > $O/i2vtests.log 2>&1; grep -E "^\[|^\.\[" $O/i2vtests.log | cut -c1-250; tail -3 $O/i2vtests.log ;;
+    share2job) SVD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --denoise-steps 2 --steps 6 --warmup 0 --no-trace --no-cpu-baseline --no-stages > $O/bench_2rank_shared_gpu.json 2>$O/share2.err; cut -c1-300 $O/bench_2rank_shared_gpu.json; grep -o '"parallelism": "[^"]*"' $O/bench_2rank_shared_gpu.json | cut -c1-400; tail -2 $O/share2.err
+              SVD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 4 --denoise-steps 2 --steps 6 --warmup 0 --no-trace --no-cpu-baseline --no-stages > $O/bench_4rank_job_shared_gpu.json 2>$O/share4.err; cut -c1-300 $O/bench_4rank_job_shared_gpu.json; grep -o '"parallelism": "[^"]*"' $O/bench_4rank_job_shared_gpu.json | cut -c1-400; tail -2 $O/share4.err ;;
     pmcff)    bash tools/pmc_ff.sh $O ;;
     *)        echo "unknown step $step" ;;
   esac
