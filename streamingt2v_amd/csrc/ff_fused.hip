@@ -54,6 +54,62 @@ constexpr int FF_LDS_W2 = 2 * FF_W1_BYTES;                     // LDS: W1 ring (
 constexpr int FF_LDS_B2 = FF_LDS_W2 + 2 * FF_W2_BYTES;
 constexpr int FF_LDS_TOTAL = FF_LDS_B2 + FF_C * 4;             // 126 208 B
 
+// Epilogue of both forms (round 6): acc[o][r] = O[row rbase + (r & 3) + 8 (r >> 2)][channel ch0 + 32 o] of this lane; + b2 (LDS, bl[32 o]), + residual, blend, store.
+// One dword (or 16-bit) access per register: 2 token rows x 128 (64) contiguous bytes per instruction.  The residual (and blend partner) loads of 4 accumulator
+// registers x NO tiles are issued together before their first use (the S^T accumulators and fragment rings are dead here).
+template <class E, int RES, bool OUT32, bool BLEND, int NO>
+__device__ __forceinline__ void ff_epilogue(const f32x16_t (&acc)[NO], int rbase, int M, int ch0, const float* bl, const void* __restrict__ R, int64_t ldr,
+                                            const void* __restrict__ S, int64_t lds, float alpha, void* __restrict__ Y, int64_t ldy) {
+    float bias[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bias[o] = bl[32 * o];
+    constexpr int G = 4;                                       // registers (token rows) per batch
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += G) {
+        int64_t trow[G];
+        float rv[G][NO], sv[BLEND ? G : 1][BLEND ? NO : 1];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = r0 + g;
+            const int t = rbase + (r & 3) + 8 * (r >> 2);
+            trow[g] = t < M ? t : M - 1;
+            if constexpr (RES == 2) {
+                const float* rp = (const float*)R + trow[g] * ldr + ch0;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) rv[g][o] = rp[32 * o];
+                if constexpr (BLEND) {
+                    const float* sp = (const float*)S + trow[g] * lds + ch0;
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) sv[g][o] = sp[32 * o];
+                }
+            } else if constexpr (RES == 1) {
+                const svd_bf16* rp = (const svd_bf16*)R + trow[g] * ldr + ch0;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) rv[g][o] = E::to_f32(rp[32 * o]);
+                if constexpr (BLEND) {
+                    const svd_bf16* sp = (const svd_bf16*)S + trow[g] * lds + ch0;
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) sv[g][o] = E::to_f32(sp[32 * o]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = r0 + g;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                float v = acc[o][r] + bias[o];
+                if constexpr (RES != 0) v += rv[g][o];
+                if constexpr (BLEND) v = alpha * sv[g][o] + (1.0f - alpha) * v;
+                if constexpr (OUT32) ((float*)Y)[trow[g] * ldy + ch0 + 32 * o] = v;
+                else ((svd_bf16*)Y)[trow[g] * ldy + ch0 + 32 * o] = E::from_f32(v);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // RES: 0 = no residual, 1 = 16-bit residual rows, 2 = fp32 residual rows (the fp32 residual stream); OUT32: fp32 output rows;
 // BLEND: Y = alpha * S + (1 - alpha) * (...) with S of the residual's type (the temporal block's AlphaBlender, video_attention.py:318-322)
 // PV (probe builds only, -DSVD_FF_PROBES; results are WRONG for PV != 0): 1 = no LDS-DMA in the steps (stale weights), 2 = no GELU arithmetic,
@@ -250,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
             for (int j = 0; j < 2 * FF_NO; ++j) {
                 if (j + 3 < 2 * FF_NO) f2[(j + 3) & 3] = *(const uint4*)(w2l + (j + 3) * 1024);
                 if constexpr (LOADX) xf[j] = *(const uint4*)(xp + 16 * j);
-                o_acc[j % FF_NO] = E::mfma(f2[j & 3], hf[j / FF_NO], o_acc[j % FF_NO]);
+                o_acc[j % FF_NO] = E::mfma(hf[j / FF_NO], f2[j & 3], o_acc[j % FF_NO]);       // O[row, channel]: H is the A operand (round 6: see the epilogue)
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (LOADX) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // the 16 DMA pieces of this step; the 20 row loads stay in flight
@@ -263,68 +319,15 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
         }
         step.template operator()<0, false, true>(nch - 2, s_a, s_b);
         step.template operator()<1, true, false>(nch - 1, s_b, s_a);
-        // ---- epilogue: lane holds row l31, channels 32 o + 8 j + 4 hi .. + 3 in o_acc[o][4 j .. 4 j + 3]
-        const int row = (tile * 128 + wave * 32 + l31);
-        if (row < M) {
-            const float* bl = (const float*)(smem + FF_LDS_B2) + 4 * hi;
-            // Residual (and blend partner) loads in batches of G, all issued before the first use: written as one load / add / store per fragment the
-            // compiler serialised the epilogue into 40 HBM round trips per tile (one load in flight: ~20 us of a 96-us tile; profiles/r05_ff_fused_epilogue_mlp.txt).
-            // The registers are there: the S^T accumulators and the fragment rings are dead here.
-            constexpr int NE = FF_NO * 4, G = BLEND ? 5 : 10;
-            static_assert(NE % G == 0, "epilogue batches");
-#pragma unroll
-            for (int g0 = 0; g0 < NE; g0 += G) {
-                float4 rv[G], sv[BLEND ? G : 1];
-                if constexpr (RES != 0) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int ch = 32 * ((g0 + g) >> 2) + 8 * ((g0 + g) & 3) + 4 * hi;
-                        if constexpr (RES == 2) {
-                            rv[g] = *(const float4*)((const float*)R + (int64_t)row * ldr + ch);
-                            if constexpr (BLEND) sv[g] = *(const float4*)((const float*)S + (int64_t)row * lds + ch);
-                        } else {
-                            const uint2 r = *(const uint2*)((const svd_bf16*)R + (int64_t)row * ldr + ch);
-                            rv[g].x = __builtin_bit_cast(float, r.x); rv[g].y = __builtin_bit_cast(float, r.y);
-                            if constexpr (BLEND) {
-                                const uint2 t = *(const uint2*)((const svd_bf16*)S + (int64_t)row * lds + ch);
-                                sv[g].x = __builtin_bit_cast(float, t.x); sv[g].y = __builtin_bit_cast(float, t.y);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const int o = (g0 + g) >> 2, j = (g0 + g) & 3;
-                    const int ch = 32 * o + 8 * j + 4 * hi;
-                    const float4 b = *(const float4*)(bl + 32 * o + 8 * j);
-                    float4 v = {o_acc[o][4 * j] + b.x, o_acc[o][4 * j + 1] + b.y, o_acc[o][4 * j + 2] + b.z, o_acc[o][4 * j + 3] + b.w};
-                    if constexpr (RES == 2) {
-                        v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w;
-                    } else if constexpr (RES == 1) {
-                        const uint32_t r0 = __builtin_bit_cast(uint32_t, rv[g].x), r1 = __builtin_bit_cast(uint32_t, rv[g].y);
-                        v.x += E::lo(r0); v.y += E::hi(r0); v.z += E::lo(r1); v.w += E::hi(r1);
-                    }
-                    if constexpr (BLEND) {
-                        const float beta = 1.0f - alpha;
-                        float4 sw;
-                        if constexpr (RES == 2) {
-                            sw = sv[g];
-                        } else {
-                            const uint32_t t0 = __builtin_bit_cast(uint32_t, sv[g].x), t1 = __builtin_bit_cast(uint32_t, sv[g].y);
-                            sw.x = E::lo(t0); sw.y = E::hi(t0); sw.z = E::lo(t1); sw.w = E::hi(t1);
-                        }
-                        v.x = alpha * sw.x + beta * v.x; v.y = alpha * sw.y + beta * v.y; v.z = alpha * sw.z + beta * v.z; v.w = alpha * sw.w + beta * v.w;
-                    }
-                    if constexpr (OUT32) {
-                        *(float4*)((float*)Y + (int64_t)row * ldy + ch) = v;
-                    } else {
-                        uint2 u; u.x = E::pack(v.x, v.y); u.y = E::pack(v.z, v.w);
-                        *(uint2*)((svd_bf16*)Y + (int64_t)row * ldy + ch) = u;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        // ---- epilogue (round 6: untransposed).  The packed GEGLU fragment has the same register image as an A operand (lane = token l31, k = 8 hi + e) and the
+        // W2 fragment as a B operand (lane = channel, k = 8 hi + e), so GEMM 2 is issued as O = H . W2^T: o_acc[o][r] = O[token (r & 3) + 8 (r >> 2) + 4 hi]
+        // [channel 32 o + l31] -- A LANE IS A CHANNEL, and one dword load / store moves 2 token rows x 128 contiguous bytes per instruction instead of 32 rows x 32 B
+        // (tools/access_pattern_bench.hip: 5.3 against 2.7 TB/s for this kernel's R-in / Y-out traffic as a plain copy at four waves per CU).  Rows past M were
+        // loaded from row M - 1 (load_x clamps) and recompute ITS values: they store duplicates to row M - 1 (no exec-mask branch per store).
+        {
+            const int rbase = tile * 128 + wave * 32 + 4 * hi;
+            const float* bl = (const float*)(smem + FF_LDS_B2) + l31;
+            ff_epilogue<E, RES, OUT32, BLEND, FF_NO>(o_acc, rbase, M, l31, bl, R, ldr, S, lds, alpha, Y, ldy);
         }
     }
     svd_wait_dma();          // the ring's last requests (chunks of a tile that does not exist) must not outlive the workgroup's LDS
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16*
                 if constexpr (!(PV & 8)) { if (j + RD - 1 < 2 * F8_NO) f2[(j + RD - 1) & (RD - 1)] = *(const uint4*)w2_piece(j + RD - 1); }
                 if constexpr (!(PV & 1)) { if (j % 3 == 1 && j / 3 < 3) dma_w2_piece(src2, dst2, j / 3); }
                 if constexpr (LOADX) { xf[2 * j] = *(const uint4*)(xp + 16 * (2 * j)); xf[2 * j + 1] = *(const uint4*)(xp + 16 * (2 * j + 1)); }
-                o_acc[j % F8_NO] = E::mfma(f2[j & (RD - 1)], j < F8_NO ? h0 : h1, o_acc[j % F8_NO]);
+                o_acc[j % F8_NO] = E::mfma(j < F8_NO ? h0 : h1, f2[j & (RD - 1)], o_acc[j % F8_NO]);       // O[row, channel] (see the four-wave kernel's epilogue)
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -534,69 +537,11 @@ __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16*
         }
         step.template operator()<0, false, true>(nch - 2, s_a, s_b);
         step.template operator()<1, true, false>(nch - 1, s_b, s_a);
-        // ---- epilogue: lane holds row l31 of the pair's 32, channels 160 q + 32 o + 8 j + 4 hi .. + 3 in o_acc[o][4 j .. 4 j + 3]
-        const int row = (tile * 128 + pair * 32 + l31);
-        if (row < M) {
-            const int cb = 160 * q + 4 * hi;
-            const float* bl = (const float*)(smem + FF_LDS_B2) + cb;
-            // Residual (and blend partner) loads in batches of G, all issued before the first use: written as one load / add / store per fragment the
-            // compiler serialised the epilogue into 40 HBM round trips per tile (one load in flight: ~20 us of a 96-us tile; profiles/r05_ff_fused_epilogue_mlp.txt).
-            // The registers are there: the S^T accumulators and the fragment rings are dead here.
-            constexpr int NE = F8_NO * 4, G = BLEND ? 5 : 10;
-            static_assert(NE % G == 0, "epilogue batches");
-#pragma unroll
-            for (int g0 = 0; g0 < NE; g0 += G) {
-                float4 rv[G], sv[BLEND ? G : 1];
-                if constexpr (RES != 0) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int ch = 32 * ((g0 + g) >> 2) + 8 * ((g0 + g) & 3) + cb;
-                        if constexpr (RES == 2) {
-                            rv[g] = *(const float4*)((const float*)R + (int64_t)row * ldr + ch);
-                            if constexpr (BLEND) sv[g] = *(const float4*)((const float*)S + (int64_t)row * lds + ch);
-                        } else {
-                            const uint2 r = *(const uint2*)((const svd_bf16*)R + (int64_t)row * ldr + ch);
-                            rv[g].x = __builtin_bit_cast(float, r.x); rv[g].y = __builtin_bit_cast(float, r.y);
-                            if constexpr (BLEND) {
-                                const uint2 t = *(const uint2*)((const svd_bf16*)S + (int64_t)row * lds + ch);
-                                sv[g].x = __builtin_bit_cast(float, t.x); sv[g].y = __builtin_bit_cast(float, t.y);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const int o = (g0 + g) >> 2, j = (g0 + g) & 3;
-                    const int ch = 32 * o + 8 * j + cb;
-                    const float4 b = *(const float4*)(bl + 32 * o + 8 * j);
-                    float4 v = {o_acc[o][4 * j] + b.x, o_acc[o][4 * j + 1] + b.y, o_acc[o][4 * j + 2] + b.z, o_acc[o][4 * j + 3] + b.w};
-                    if constexpr (RES == 2) {
-                        v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w;
-                    } else if constexpr (RES == 1) {
-                        const uint32_t r0 = __builtin_bit_cast(uint32_t, rv[g].x), r1 = __builtin_bit_cast(uint32_t, rv[g].y);
-                        v.x += E::lo(r0); v.y += E::hi(r0); v.z += E::lo(r1); v.w += E::hi(r1);
-                    }
-                    if constexpr (BLEND) {
-                        const float beta = 1.0f - alpha;
-                        float4 sw;
-                        if constexpr (RES == 2) {
-                            sw = sv[g];
-                        } else {
-                            const uint32_t t0 = __builtin_bit_cast(uint32_t, sv[g].x), t1 = __builtin_bit_cast(uint32_t, sv[g].y);
-                            sw.x = E::lo(t0); sw.y = E::hi(t0); sw.z = E::lo(t1); sw.w = E::hi(t1);
-                        }
-                        v.x = alpha * sw.x + beta * v.x; v.y = alpha * sw.y + beta * v.y; v.z = alpha * sw.z + beta * v.z; v.w = alpha * sw.w + beta * v.w;
-                    }
-                    if constexpr (OUT32) {
-                        *(float4*)((float*)Y + (int64_t)row * ldy + ch) = v;
-                    } else {
-                        uint2 u; u.x = E::pack(v.x, v.y); u.y = E::pack(v.z, v.w);
-                        *(uint2*)((svd_bf16*)Y + (int64_t)row * ldy + ch) = u;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        // ---- epilogue: o_acc[o][r] = O[token (r & 3) + 8 (r >> 2) + 4 hi of the pair's 32][channel 160 q + 32 o + l31] (untransposed: see the four-wave kernel)
+        {
+            const int rbase = tile * 128 + pair * 32 + 4 * hi;
+            const float* bl = (const float*)(smem + FF_LDS_B2) + 160 * q + l31;
+            ff_epilogue<E, RES, OUT32, BLEND, F8_NO>(o_acc, rbase, M, 160 * q + l31, bl, R, ldr, S, lds, alpha, Y, ldy);
         }
     }
     svd_wait_dma();

@@ -5,7 +5,7 @@ StreamingWrapper.forward on CFG 2 x 25 frames @ 72x128 latent with ControlNet on
 -> 576x1024), wrapper_fullarch.pt / i2v_fullarch.pt / vae_fullarch.pt / vae_enc_fullarch.pt (shipped architecture on a small latent).
 
 Tolerance statement (absolute per-frame L2 = RMS error of a frame; values measured on MI355X, profiles/r04_fullsize_parity_plans.txt, _level0.txt):
-  * row A11 (decoder, full size): fp16 8.9e-4 -> asserted <= 1e-3, north_star's bound.
+  * row A11 (decoder, full size): fp16 8.9e-4 (round 6, decoder precision plan: 5.2e-4) -> asserted <= 1e-3, north_star's bound.
   * row A5 (StreamingWrapper.forward, full size, fp16), the PACKAGE DEFAULT (round 4: the precision plan of streamingt2v_amd/ops.py -- split-3 rim
     + fp32 residual stream in both networks): 0.757e-3 mean / 0.911e-3 max -> asserted mean <= 1e-3 AND max <= 1e-3: north_star's literal bound on
     every frame, in the configuration bench.py times.
@@ -26,9 +26,12 @@ oracle/make_golden_i2v_fullarch.py --fullres, the unmodified reference modules o
     deviation (0.76e-3 at sigma 700, where c_out = -1 and the denoised latent IS the network output) multiplied by classifier-free guidance:
     D = D_u + s (D_c - D_u) carries independent errors of both halves, sqrt(s^2 + (s - 1)^2) = 1.6 .. 3.6 for s = 1.5 .. 3.0 over the 25 frames
     (mean 2.5 -> 1.9e-3 on the latents, exactly what is measured), and the decoder's contraction.  No 16-bit-operand execution can be closer
-    (the reference's own fp16 autocast deviates 1.42e-3 per evaluation, wrapper_fullsize_autocast.json).  Asserted: 1.5e-3 on the decoded frames,
-    3.2e-3 on the latents -- and, when tests/golden/chunk_fullsize_autocast.json is present (oracle/make_golden_fullsize.py --which chunk_autocast:
-    the REFERENCE'S OWN fp16-autocast execution of the same chunk; hours of CPU), no further from the fp32 run than that.
+    (the reference's own fp16 autocast deviates 1.42e-3 per evaluation, wrapper_fullsize_autocast.json).
+Round 6: the composed chunk is asserted against the ENVELOPE of the reference's shipped precision instead of hand-set numbers -- tests/golden/chunk_fullsize_autocast.json
+(oracle/make_golden_fullsize_gpu.py: fp16-autocast execution against fp32 of the same computation; 2-step chunk: frames 1.72e-3 max / 1.58e-3 mean, latents 4.86e-3 / 3.35e-3) --
+and a WHOLE chunk (30 steps, 25 decoded frames) plus the autoregressive hand-over into the next chunk are compared the same way (test_chunk_full_size_vs_reference).
+The decoder's precision plan (ops.AE_*) exists because of that comparison: with the 16-bit decoder the latents were 22 % inside the envelope and the decoded frames' mean 3 %
+outside it (profiles/r06_fullsize_chunk_tests.txt) -- the reference decodes in fp32 (config.yaml:310).
 """
 import pytest
 import torch
@@ -162,7 +165,8 @@ def test_shipped_architecture_small_latent_vs_reference(dtype, golden_dir):
         k = 1.0 if f16 else 9.0          # bf16: one rounding is 8x coarser
         # StreamingWrapper (A5), VideoUNet without control (A7) and -- round 5 -- I2VGenXLUNet (A12) under their default precision plans: north_star's 1e-3
         # (measured 0.76e-3 / 0.69e-3 / 0.907e-3)
-        assert e_w <= 1e-3 * k and e_u <= 1e-3 * k and e_i2v <= 1e-3 * k and e_dec <= 1.3e-3 * k and e_enc <= 1.2e-3 * k
+        # round 6: the VideoDecoder under its precision plan (ops.AE_EXACT_RIM, AE_STREAM_F32_MIN_CH = 128: 0.64e-3) and the Encoder (0.91e-3) hold the same bound
+        assert e_w <= 1e-3 * k and e_u <= 1e-3 * k and e_i2v <= 1e-3 * k and e_dec <= 1e-3 * k and e_enc <= 1e-3 * k
     finally:
         ops.set_element_dtype(None)
         torch.cuda.empty_cache()
