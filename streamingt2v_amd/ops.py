@@ -414,7 +414,14 @@ def rowgemm_ok(x, w_img, rows_per_vec=0):
     return ROWGEMM and w_img is not None and x.shape[1] == 320 and (rows_per_vec == 0 or rows_per_vec % 32 == 0)
 
 
-def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True):
+# ZERO-COPY CONCATENATION (round 6): the decoder half's torch.cat([h, hs.pop()], 1) (video_model.py:606-611) is a 16-bit GEMM operand.  Where the tensor a layer
+# produces is consumed by that concatenation ONLY (a decoder block's output, an Upsample output, a CAM merger's output), the layer's last kernel writes its
+# 16-bit rounding straight into its column range of the concatenation buffer instead of an fp32 tensor that svd_cast_rows_f32 rounds afterwards: the same bits
+# (one rounding of the same fp32 value), 8 bytes per element less HBM traffic.  SVD_ZERO_COPY_CONCAT=0 restores the copies (A/B).
+ZERO_COPY_CONCAT = _os.environ.get("SVD_ZERO_COPY_CONCAT", "1") != "0"
+
+
+def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True, out=None):
     """x [M, 320] 16-bit rows; w_img = video_model.pack_rowgemm320(W) on the device (uint8).  Returns (y, yn): y = residual + bias + rowvec[row // rows_per_vec]
     + x W^T (fp32 rows when out_f32, else 16 bit; None when want_y is False), yn = LayerNorm(y) * ln[0] + ln[1] in the 16-bit type (None without ln)."""
     assert x.dtype in (BF16, F16) and x.is_cuda and x.stride(1) == 1 and x.shape[1] == 320 and w_img.dtype == torch.uint8
@@ -424,7 +431,10 @@ def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=Non
     if rowvec is not None:
         assert rowvec.dtype == torch.float32 and rowvec.stride(-1) == 1 and rows_per_vec % 32 == 0 and rows_per_vec > 0
     assert want_y or ln is not None
-    y = torch.empty((M, 320), dtype=torch.float32 if out_f32 else x.dtype, device=x.device) if want_y else None
+    if out is not None:          # a caller-owned (possibly strided) destination, e.g. a column range of a concatenation buffer
+        assert want_y and out.shape == (M, 320) and out.stride(1) == 1 and out.dtype in (torch.float32, x.dtype) and out.is_cuda
+        out_f32 = out.dtype == torch.float32
+    y = out if out is not None else (torch.empty((M, 320), dtype=torch.float32 if out_f32 else x.dtype, device=x.device) if want_y else None)
     yn = torch.empty((M, 320), dtype=x.dtype, device=x.device) if ln is not None else None
     g, b = ln if ln is not None else (None, None)
     flops = 2.0 * M * 320 * 320

@@ -436,9 +436,11 @@ class SpatialVideoTransformer:
             self._a2c = c = (ctx, tctx, ops.ELEM, v2, v2t)
         return c[3], c[4]
 
-    def forward(self, x, ctx, tctx, F, T, H, W, sp=None):
+    def forward(self, x, ctx, tctx, F, T, H, W, sp=None, out16=None):
         """x [F*H*W, C]; ctx [F, ctx_dim] bf16 (per-frame CLIP token); tctx [B, ctx_dim] (= context[::T]).  With `sp`
-        (parallel.SeqParallel) x / ctx hold this rank's frames; the temporal block runs in the pixel layout."""
+        (parallel.SeqParallel) x / ctx hold this rank's frames; the temporal block runs in the pixel layout.
+        out16: a 16-bit [rows, C] view (a column range of the next block's concatenation buffer, ops.ZERO_COPY_CONCAT): when the block's output is consumed by that
+        concatenation only, proj_out writes its rounding there directly where the row-owning kernel applies; the view is returned then, else the usual tensor."""
         c, heads, pix = self.c, self.heads, H * W
         M, B = F * pix, tctx.shape[0]
         st = ops.stream_on(c, "svt")  # fp32 residual stream: h, xm and the output are fp32 between the kernels; every GEMM / attention operand is 16 bit
@@ -514,7 +516,7 @@ class SpatialVideoTransformer:
         # proj_out has no LayerNorm behind it; the row-owning kernel still moves its rows faster than the 256 x 320 tile on the large token matrices
         # (307 vs 353 us at M = 460 800, 667 vs 781 us at 1 094 400; 111 vs 107 us at 129 024: profiles/r06_rowgemm_probe_v2.txt)
         if rg is not None and M >= ops.ROWGEMM_PLAIN_MIN_ROWS:
-            return ops.rowgemm320(xb, rg["po"], bias=self.bpo, residual=x)[0]
+            return ops.rowgemm320(xb, rg["po"], bias=self.bpo, residual=x, out=out16)[0]
         return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out_f32=out32)
 
 
@@ -542,8 +544,10 @@ class ConditionalModel:
         self.wq = _dev_bf16(g("attention.to_q.weight"), dev)
         self.wkv = _dev_bf16(torch.cat([g("attention.to_k.weight"), g("attention.to_v.weight")], 0), dev)
         self.wo, self.bo = _dev_bf16(g("attention.to_out.0.weight"), dev), _dev_f32(g("attention.to_out.0.bias"), dev)
+        self.rg_po = pack_rowgemm320(g("proj_out.weight")).to(dev) if self.c == 320 else None          # proj_out + residual straight into a concatenation buffer (out16)
+        self.rg_dtype = ops.ELEM
 
-    def forward(self, sample, cond, F, T, Tc, H, W, sp=None):
+    def forward(self, sample, cond, F, T, Tc, H, W, sp=None, out16=None):
         """sample [F*pix, C] (F = B * frames held by this rank), cond [B*Tc(local)*pix, C] ControlNet features.  With `sp` the queries are
         this rank's frames, the 7 conditioning frames' K / V are all-gathered (they are sharded like the ControlNet that made them), and
         the 5-D GroupNorm sums are all-reduced."""
@@ -567,6 +571,9 @@ class ConditionalModel:
         ops.attn_temporal(q, kv[:, :c], kv[:, c:], a, B, Tq, Tc, pix, self.heads)
         a = ops.gemm(a, self.wo, bias=self.bo)
         # dropout(p=.25) on the non-conditional frames is identity in eval mode (conditioning.py:74-75)
+        if (out16 is not None and self.rg_po is not None and sample.dtype == torch.float32 and a.dtype == self.rg_dtype and a.shape[0] >= ops.ROWGEMM_PLAIN_MIN_ROWS
+                and ops.rowgemm_ok(a, self.rg_po)):
+            return ops.rowgemm320(a, self.rg_po, bias=self.bpo, residual=sample, out=out16)[0]         # sample + proj_out(..), rounded once, in its consumer's buffer
         return ops.gemm(a, self.wpo, bias=self.bpo, residual=sample, out_f32=sample.dtype == torch.float32)
 
 
@@ -741,17 +748,23 @@ class _EncoderBase:
         self._emb_w, self._emb_b = torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()
 
     @staticmethod
-    def _run(layers, h, emb_silu, ctx, tctx, F, T, H, W, sp=None, emb_full=None):
-        """emb_silu / emb_full: rows of the local / of all frames of the PACKED emb_layers output (see _local_conditioning)."""
-        for m in layers:
+    def _run(layers, h, emb_silu, ctx, tctx, F, T, H, W, sp=None, emb_full=None, out16_of=None):
+        """emb_silu / emb_full: rows of the local / of all frames of the PACKED emb_layers output (see _local_conditioning).
+        out16_of(rows) -> a 16-bit [rows, C] view or None: where the LAST layer may write its output directly (zero-copy concatenation)."""
+        for i, m in enumerate(layers):
+            last = out16_of is not None and i == len(layers) - 1
             if isinstance(m, VideoResBlock):
                 h = m.forward(h, None, F, T, H, W, sp=sp, emb_out=(emb_silu, emb_full))
             elif isinstance(m, SpatialVideoTransformer):
-                h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp)
+                h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp, out16=out16_of(h.shape[0]) if last else None)
             else:
                 # stem / Downsample / Upsample convolutions write the stream; the only rim convolution here is the stem (x3=True), and a rim stem
                 # (w3) is always fed the split-3 rows input_tokens() makes for it
-                h, H, W = m.forward(h, F, H, W, split3=m.w3 is not None, out_f32=ops.stream_on(m.cout))
+                view = out16_of(h.shape[0] * (4 if m.ups else 1)) if (last and m.w3 is None and sp is None) else None
+                if view is not None:
+                    h, H, W = m.forward(h, F, H, W, out=view)          # an Upsample output consumed by the concatenation only: 16 bit, in place
+                else:
+                    h, H, W = m.forward(h, F, H, W, split3=m.w3 is not None, out_f32=ops.stream_on(m.cout))
         return h, H, W
 
     def _local_conditioning(self, timesteps, context, y, T, sp):
@@ -869,6 +882,32 @@ class VideoUNet(_EncoderBase):
         emb_silu, emb_full, ctx, tctx, F = self._local_conditioning(timesteps, context, y, T, sp)
         assert x_tok.shape[0] == F * H * W
         kw = dict(sp=sp, emb_full=emb_full)
+        # ---- zero-copy concatenation (ops.ZERO_COPY_CONCAT): one 16-bit buffer [rows, cin] per output block; producers whose result only that block's
+        # torch.cat consumes write their column range directly, everything else is rounded into it by cat() exactly as ops.concat_channels did
+        n_out = len(self.output_blocks)
+        bufs = [None] * n_out
+
+        def cat_view(j, rows, ch, right):
+            if not ops.ZERO_COPY_CONCAT or j >= n_out:
+                return None
+            total = self.output_blocks[j][0].cin
+            if bufs[j] is None:
+                bufs[j] = torch.empty((rows, total), dtype=ops.ELEM, device=x_tok.device)
+            b = bufs[j]
+            assert b.shape[0] == rows
+            return b[:, total - ch:] if right else b[:, :ch]
+
+        def cat(j, a, b):
+            buf = bufs[j]
+            if buf is None or buf.shape[1] != a.shape[1] + b.shape[1] or buf.shape[0] != a.shape[0]:
+                return ops.concat_channels(a, b)
+            same = lambda t, v: t.dtype == v.dtype and t.data_ptr() == v.data_ptr() and t.stride(0) == v.stride(0) and t.shape == v.shape
+            va, vb = buf[:, :a.shape[1]], buf[:, a.shape[1]:]
+            if not same(a, va):
+                ops.to_elem_rows(a, out=va)
+            if not same(b, vb):
+                ops.to_elem_rows(b, out=vb)
+            return buf
         hs = []
         h = x_tok
         for blk in self.input_blocks:
@@ -878,17 +917,23 @@ class VideoUNet(_EncoderBase):
             # CAM: merge ControlNet features into every skip tensor (video_model.py:582-591)
             assert len(hs) == len(hs_control_input) == len(self.cross_attention_merger_input_blocks)
             Tc = num_conditional_frames
-            hs = [(mg.forward(hh, hc, F, T, Tc, Hh, Wh, sp=sp), Hh, Wh)
-                  for (hh, Hh, Wh), hc, mg in zip(hs, hs_control_input, self.cross_attention_merger_input_blocks)]
+            merged = []
+            for i, ((hh, Hh, Wh), hc, mg) in enumerate(zip(hs, hs_control_input, self.cross_attention_merger_input_blocks)):
+                # the merged skip tensor is consumed by the concatenation in front of output block n - 1 - i only: its 16-bit rounding goes straight
+                # into the right-hand columns of that block's buffer where the merger can write it (zero-copy concatenation)
+                view = cat_view(n_out - 1 - i, hh.shape[0], hh.shape[1], right=True)
+                merged.append((mg.forward(hh, hc, F, T, Tc, Hh, Wh, sp=sp, out16=view), Hh, Wh))
+            hs = merged
         # middle_block consumes the UN-merged encoder output (video_model.py:593-600)
         h, H, W = self._run(self.middle_block, h, emb_silu, ctx, tctx, F, T, H, W, **kw)
         if hs_control_mid is not None:
             h = self.cross_attention_merger_mid_block.forward(h, hs_control_mid, F, T, num_conditional_frames, H, W, sp=sp)
-        for blk in self.output_blocks:
+        for j, blk in enumerate(self.output_blocks):
             skip, Hs, Ws = hs.pop()
             assert (Hs, Ws) == (H, W)
-            h = ops.concat_channels(h, skip)
-            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, **kw)
+            h = cat(j, h, skip)
+            nxt = (lambda rows, j=j, c=blk[0].cout: cat_view(j + 1, rows, c, right=False)) if j + 1 < n_out else None
+            h, H, W = self._run(blk, h, emb_silu, ctx, tctx, F, T, H, W, out16_of=nxt, **kw)
         if self.head_wt is not None:        # GroupNorm + SiLU + conv to 4 channels as one fp32 kernel (precision plan; also faster than a 4-wide MFMA tile)
             out = ops.head_gn_silu_conv3x3(h, F, H, W, self.ow, self.ob, 1e-5, self.head_wt, self.head_b, self.out_channels)
         else:

@@ -339,7 +339,7 @@ def _rowgemm_unpack(img, dtype):
     return w
 
 
-def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True):
+def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True, out=None):
     """csrc/rowgemm.hip: y = residual + bias + rowvec[row // rows_per_vec] + x W^T; yn = LayerNorm(y) (include/svdhip.h svd_rowgemm320)."""
     if not hasattr(w_img, "_rg_unpacked"):
         w_img._rg_unpacked = _rowgemm_unpack(w_img, x.dtype)
@@ -351,6 +351,9 @@ def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=Non
     if residual is not None:
         y = y + residual.float()
     yn = F.layer_norm(y, (320,), ln[0], ln[1], eps).to(x.dtype) if ln is not None else None
+    if out is not None:
+        out.copy_(y.to(out.dtype))
+        return out, yn
     return ((y if out_f32 else y.to(x.dtype)) if want_y else None), yn
 
 

@@ -788,3 +788,24 @@ def test_stock_svd_xt_key_maps_and_folder_loader(tmp_path):
     save_file(sd, f)
     with pytest.raises(KeyError, match="no tensor"):
         P.load_stock_svd_xt(str(tmp_path), device="cpu")
+
+
+def test_rowgemm320_weight_image_layout_and_round_trip():
+    """video_model.pack_rowgemm320 (the image svd_rowgemm320 reads, include/svdhip.h): fragment 10 s + o, lane l, element e = W[32 o + l % 32][16 s + 8 (l // 32) + e];
+    tests/svd_shim._rowgemm_unpack (the CPU statement of the kernel's view of it) inverts it exactly."""
+    import torch
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.video_model import pack_rowgemm320
+    from tests import svd_shim
+    prev = ops.ELEM
+    ops.ELEM = torch.float32
+    try:
+        w = torch.arange(320 * 320, dtype=torch.float32).reshape(320, 320)          # every element distinct: W[n][k] = 320 n + k
+        img = pack_rowgemm320(w)
+        assert img.dtype == torch.uint8 and img.numel() == 200 * 64 * 8 * 4
+        f = img.view(torch.float32).view(20, 10, 64, 8)
+        for s_, o, l, e in ((0, 0, 0, 0), (3, 7, 37, 5), (19, 9, 63, 7), (5, 0, 31, 0), (4, 9, 32, 3)):
+            assert f[s_, o, l, e].item() == 320 * (32 * o + l % 32) + 16 * s_ + 8 * (l // 32) + e
+        assert torch.equal(svd_shim._rowgemm_unpack(img, torch.float32), w)
+    finally:
+        ops.ELEM = prev
