@@ -419,6 +419,9 @@ def rowgemm_ok(x, w_img, rows_per_vec=0):
 # 16-bit rounding straight into its column range of the concatenation buffer instead of an fp32 tensor that svd_cast_rows_f32 rounds afterwards: the same bits
 # (one rounding of the same fp32 value), 8 bytes per element less HBM traffic.  SVD_ZERO_COPY_CONCAT=0 restores the copies (A/B).
 ZERO_COPY_CONCAT = _os.environ.get("SVD_ZERO_COPY_CONCAT", "1") != "0"
+# ... also through svd_gemm's GENERIC epilogue (fp32 residual in, 16-bit rows out: proj_out of the 640 / 1280-channel transformers and mergers, the last temporal
+# convolution of a ResBlock that ends a decoder block)
+ZERO_COPY_GENERIC = _os.environ.get("SVD_ZERO_COPY_GENERIC", "1") != "0"          # measured: +0.3 % on the stage-1 line, identical results (profiles/r06_bench6_zero_copy_generic_ab.txt)
 
 
 def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True, out=None):

@@ -228,7 +228,7 @@ class VideoResBlock:
         self.tw2 = _dev_bf16(pack_tconv3(g(t + "out_layers.3.weight")) * (1.0 - self.alpha), dev)
         self.tb2 = _dev_f32(g(t + "out_layers.3.bias").detach().float() * (1.0 - self.alpha), dev)
 
-    def forward(self, x, emb_silu, F, T, H, W, sp=None, emb_full=None, emb_out=None):
+    def forward(self, x, emb_silu, F, T, H, W, sp=None, emb_full=None, emb_out=None, out16=None):
         """x [F*H*W, C]: the frames this rank holds (all B*T of them without sequence parallelism; then emb_silu is also the
         embedding of all frames).  With `sp` (parallel.SeqParallel): emb_silu = embedding rows of the LOCAL frames (2-D part),
         emb_full = rows of all B*T frames (the time_stack runs in the pixel layout, where every rank sees all frames).
@@ -256,6 +256,8 @@ class VideoResBlock:
             g = ops.gemm(g, self.tw1, bias=self.tb1, rowvec=et, rows_per_vec=pix, temporal=tv)
             g = ops.groupnorm(g, F, pix, self.tn2w, self.tn2b, 1e-5, frames_per_stat=T, silu=True)
             # out = alpha * x_spatial + (1 - alpha) * (conv + bias + identity skip) = x_spatial + [(1 - alpha) conv + (1 - alpha) bias]  (prepare)
+            if out16 is not None and ops.ZERO_COPY_GENERIC:          # the block's output feeds a concatenation only: its 16-bit rounding, in place
+                return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, temporal=tv, out=out16)
             return ops.gemm(g, self.tw2, bias=self.tb2, residual=hs, temporal=tv, out_f32=st)
         # sequence parallel: the whole time_stack in the PIXEL layout (all T frames of this rank's pixel range); its two norms pool
         # over every frame and pixel -> all-reduce of the sums
@@ -517,6 +519,8 @@ class SpatialVideoTransformer:
         # (307 vs 353 us at M = 460 800, 667 vs 781 us at 1 094 400; 111 vs 107 us at 129 024: profiles/r06_rowgemm_probe_v2.txt)
         if rg is not None and M >= ops.ROWGEMM_PLAIN_MIN_ROWS:
             return ops.rowgemm320(xb, rg["po"], bias=self.bpo, residual=x, out=out16)[0]
+        if out16 is not None and ops.ZERO_COPY_GENERIC and sp is None:
+            return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out=out16)
         return ops.gemm(xb, self.wpo, bias=self.bpo, residual=x, out_f32=out32)
 
 
@@ -574,6 +578,8 @@ class ConditionalModel:
         if (out16 is not None and self.rg_po is not None and sample.dtype == torch.float32 and a.dtype == self.rg_dtype and a.shape[0] >= ops.ROWGEMM_PLAIN_MIN_ROWS
                 and ops.rowgemm_ok(a, self.rg_po)):
             return ops.rowgemm320(a, self.rg_po, bias=self.bpo, residual=sample, out=out16)[0]         # sample + proj_out(..), rounded once, in its consumer's buffer
+        if out16 is not None and ops.ZERO_COPY_GENERIC:
+            return ops.gemm(a, self.wpo, bias=self.bpo, residual=sample, out=out16)
         return ops.gemm(a, self.wpo, bias=self.bpo, residual=sample, out_f32=sample.dtype == torch.float32)
 
 
@@ -754,7 +760,7 @@ class _EncoderBase:
         for i, m in enumerate(layers):
             last = out16_of is not None and i == len(layers) - 1
             if isinstance(m, VideoResBlock):
-                h = m.forward(h, None, F, T, H, W, sp=sp, emb_out=(emb_silu, emb_full))
+                h = m.forward(h, None, F, T, H, W, sp=sp, emb_out=(emb_silu, emb_full), out16=out16_of(h.shape[0]) if (last and sp is None) else None)
             elif isinstance(m, SpatialVideoTransformer):
                 h = m.forward(h, ctx, tctx, F, T, H, W, sp=sp, out16=out16_of(h.shape[0]) if last else None)
             else:
