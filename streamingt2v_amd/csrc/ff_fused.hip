@@ -58,11 +58,11 @@ constexpr int FF_LDS_TOTAL = FF_LDS_B2 + FF_C * 4;             // 126 208 B
 // One dword (or 16-bit) access per register: 2 token rows x 128 (64) contiguous bytes per instruction.  The residual (and blend partner) loads of 4 accumulator
 // registers x NO tiles are issued together before their first use (the S^T accumulators and fragment rings are dead here).
 template <class E, int RES, bool OUT32, bool BLEND, int NO>
-__device__ __forceinline__ void ff_epilogue(const f32x16_t (&acc)[NO], int rbase, int M, int ch0, const float* bl, const void* __restrict__ R, int64_t ldr,
-                                            const void* __restrict__ S, int64_t lds, float alpha, void* __restrict__ Y, int64_t ldy) {
-    float bias[NO];
+__device__ __forceinline__ void ff_epilogue(const f32x16_t (&acc)[NO], int rbase, int M, int ch0, const float* bl, const float* rv, const void* __restrict__ R,
+                                            int64_t ldr, const void* __restrict__ S, int64_t lds, float alpha, void* __restrict__ Y, int64_t ldy) {
+    float bias[NO];          // b2 + the per-frame vector of this wave's 32 rows (rv: already at the frame's row and this lane's channel; NULL = none)
 #pragma unroll
-    for (int o = 0; o < NO; ++o) bias[o] = bl[32 * o];
+    for (int o = 0; o < NO; ++o) bias[o] = bl[32 * o] + (rv ? rv[32 * o] : 0.f);
     constexpr int G = 4;                                       // registers (token rows) per batch
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += G) {
@@ -118,7 +118,8 @@ template <class E, int RES, bool OUT32, bool BLEND = false, int PV = 0>
 __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp, int nch,
                                                                 const float* __restrict__ b2, const void* __restrict__ R, int64_t ldr,
                                                                 const void* __restrict__ S, int64_t lds, float alpha,
-                                                                void* __restrict__ Y, int64_t ldy, int M, int ntiles) {
+                                                                void* __restrict__ Y, int64_t ldy, int M, int ntiles,
+                                                                const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ff_start_delay();
     const uint32_t sbase = lds_addr_of(smem);
@@ -327,7 +328,10 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
         {
             const int rbase = tile * 128 + wave * 32 + 4 * hi;
             const float* bl = (const float*)(smem + FF_LDS_B2) + l31;
-            ff_epilogue<E, RES, OUT32, BLEND, FF_NO>(o_acc, rbase, M, l31, bl, R, ldr, S, lds, alpha, Y, ldy);
+            // rows_per_vec % 32 == 0: one vector per wave; a wave wholly past M recomputes row M - 1 and must take ITS vector (its stores are duplicates of that row)
+            const int vrow = tile * 128 + wave * 32 < M ? tile * 128 + wave * 32 : M - 1;
+            const float* rv = rowvec ? rowvec + (int64_t)(vrow / rows_per_vec) * rowvec_ld + l31 : nullptr;
+            ff_epilogue<E, RES, OUT32, BLEND, FF_NO>(o_acc, rbase, M, l31, bl, rv, R, ldr, S, lds, alpha, Y, ldy);
         }
     }
     svd_wait_dma();          // the ring's last requests (chunks of a tile that does not exist) must not outlive the workgroup's LDS
@@ -359,7 +363,8 @@ template <class E, int RES, bool OUT32, bool BLEND = false, int PV = 0>
 __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp, int nch,
                                                                  const float* __restrict__ b2, const void* __restrict__ R, int64_t ldr,
                                                                  const void* __restrict__ S, int64_t lds, float alpha,
-                                                                 void* __restrict__ Y, int64_t ldy, int M, int ntiles) {
+                                                                 void* __restrict__ Y, int64_t ldy, int M, int ntiles,
+                                                                 const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t sbase = lds_addr_of(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -541,7 +546,9 @@ __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16*
         {
             const int rbase = tile * 128 + pair * 32 + 4 * hi;
             const float* bl = (const float*)(smem + FF_LDS_B2) + 160 * q + l31;
-            ff_epilogue<E, RES, OUT32, BLEND, F8_NO>(o_acc, rbase, M, 160 * q + l31, bl, R, ldr, S, lds, alpha, Y, ldy);
+            const int vrow = tile * 128 + pair * 32 < M ? tile * 128 + pair * 32 : M - 1;          // (see the four-wave kernel)
+            const float* rv = rowvec ? rowvec + (int64_t)(vrow / rows_per_vec) * rowvec_ld + 160 * q + l31 : nullptr;
+            ff_epilogue<E, RES, OUT32, BLEND, F8_NO>(o_acc, rbase, M, 160 * q + l31, bl, rv, R, ldr, S, lds, alpha, Y, ldy);
         }
     }
     svd_wait_dma();
@@ -561,7 +568,8 @@ extern "C" { int svd_ff_probe_variant = 0; }      // 1..4 / 101..116: timing pro
 #endif
 extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t channels, int32_t hidden, const float* b2, const void* R,
                                   int64_t ldr, const void* S, int64_t lds, float alpha, int32_t res_f32, void* Y, int64_t ldy, int32_t out_f32, int64_t M,
-                                  int32_t dtype, svd_stream_t stream) {
+                                  int32_t dtype, const float* rowvec, int32_t rowvec_ld, int32_t rows_per_vec, svd_stream_t stream) {
+    if (rowvec && (rows_per_vec <= 0 || rows_per_vec % 32 || rowvec_ld < FF_C)) return SVD_EINVAL;
     if (!X || !Wp || !b2 || !Y || M <= 0 || M > 0x7fffff00 || channels != FF_C || hidden <= 0 || hidden % 64) return SVD_EINVAL;
     if (ldx % 8 || ldx < FF_C || ldy < FF_C || (R && ldr < FF_C)) return SVD_EINVAL;
     if (((uintptr_t)X | (uintptr_t)Wp) & 15) return SVD_EINVAL;
@@ -600,7 +608,7 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
                     attr_set = true;                                                                                                     \
                 }                                                                                                                        \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
-                                   alpha, Y, ldy, (int)M, ntiles);                                                                                      \
+                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec);                                                                                      \
             } else {                                                                                                                     \
                 auto kern = ff_geglu_fused8_kernel<E, RES, OUT, BL>;                                                                      \
                 static unsigned char attr_set_dev[64] = {0};                                                                             \
@@ -610,7 +618,7 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
                     attr_set = true;                                                                                                     \
                 }                                                                                                                        \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
-                                   alpha, Y, ldy, (int)M, ntiles);                                                                                      \
+                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec);                                                                                      \
             }                                                                                                                            \
         });                                                                                                                              \
     } while (0)
@@ -620,13 +628,13 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
         do {                                                                                                                             \
             auto kern = ff_geglu_fused_kernel<ElemF16, 2, true, false, PVV>;                                                                   \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec); \
         } while (0)
 #define FF_PROBE8(PVV)                                                                                                                   \
         do {                                                                                                                             \
             auto kern = ff_geglu_fused8_kernel<ElemF16, 2, true, false, PVV>;                                                              \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec); \
         } while (0)
         switch (svd_ff_probe_variant) {
             case 1: FF_PROBE(1); break; case 2: FF_PROBE(2); break; case 3: FF_PROBE(3); break; case 4: FF_PROBE(4); break;

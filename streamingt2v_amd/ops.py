@@ -371,7 +371,7 @@ def ff_fused_ok(channels, hidden):
     return FF_FUSED and channels == 320 and hidden % 64 == 0
 
 
-def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None):
+def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None, rowvec=None, rows_per_vec=0):
     """x [M, 320] 16-bit rows; img = video_model.pack_ff_fused(...) on the device (uint8); b2 [320] fp32; residual [M, 320] (16 bit or fp32);
     blend = (alpha, S) like ops.gemm.  Returns residual + b2 + W2 (value * gelu(gate)) [blended], fp32 when out_f32 else 16 bit."""
     assert x.dtype in (BF16, F16) and x.is_cuda and x.stride(1) == 1 and x.shape[1] == 320 and img.dtype == torch.uint8
@@ -393,7 +393,10 @@ def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=Fal
     if worklog is not None:
         _wl("ff_geglu_fused_kernel", flops, nbytes)
     args = (_p(x), x.stride(0), _p(img), Cc, hidden, _p(b2), _p(R), R.stride(0) if R is not None else 0, _p(S), S.stride(0) if S is not None else 0,
-            float(alpha), int(bool(r32)), _p(out), out.stride(0), int(out.dtype == torch.float32), M, _dt(x), _stream())
+            float(alpha), int(bool(r32)), _p(out), out.stride(0), int(out.dtype == torch.float32), M, _dt(x),
+            _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_vec, _stream())
+    if rowvec is not None:
+        assert rowvec.dtype == torch.float32 and rowvec.stride(-1) == 1 and rows_per_vec > 0 and rows_per_vec % 32 == 0
     if trace is not None:
         with trace.launch("ff_fused_c320", flops=flops, sig=f"ff_M{M}_C{Cc}_H{hidden}_r{int(bool(r32)) if R is not None else 'n'}_o{int(out.dtype == torch.float32)}", nbytes=nbytes):
             check(_lib.svd_ff_geglu_fused(*args), "svd_ff_geglu_fused")

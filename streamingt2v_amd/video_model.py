@@ -140,14 +140,15 @@ class FeedForward:
         self.img = pack_ff_fused(w1r, b1r, w2r).to(dev) if ops.ff_fused_ok(self.c, self.hidden) else None
         self.img_dtype = ops.ELEM          # the packed image is an opaque byte blob in THIS element type: the kernel must be launched with the same one
 
-    def __call__(self, x, residual=None, out_f32=False, blend=None):
-        if self.img is not None and ops.FF_FUSED:
+    def __call__(self, x, residual=None, out_f32=False, blend=None, rowvec=None, rows_per_vec=0):
+        """rowvec / rows_per_vec: a per-frame vector added to the result (residual + rowvec + ff(x)): `x + time_pos_embed` without materialising the sum."""
+        if self.img is not None and ops.FF_FUSED and (rowvec is None or rows_per_vec % 32 == 0):
             if x.dtype != self.img_dtype:
                 raise TypeError(f"fused feed-forward weights were packed as {self.img_dtype} (ops.ELEM at load_state_dict) but the activations are {x.dtype}: "
                                 f"call ops.set_element_dtype BEFORE load_state_dict")
-            return ops.ff_geglu_fused(x, self.img, self.hidden, self.b2, residual=residual, blend=blend, out_f32=out_f32)
+            return ops.ff_geglu_fused(x, self.img, self.hidden, self.b2, residual=residual, blend=blend, out_f32=out_f32, rowvec=rowvec, rows_per_vec=rows_per_vec)
         g = ops.gemm(x, self.w1, bias=self.b1, geglu=True)
-        return ops.gemm(g, self.w2, bias=self.b2, residual=residual, blend=blend, out_f32=out_f32)
+        return ops.gemm(g, self.w2, bias=self.b2, rowvec=rowvec, rows_per_vec=rows_per_vec, residual=residual, blend=blend, out_f32=out_f32)
 
 
 def pack_x3(w2d, taps):
@@ -477,8 +478,11 @@ class SpatialVideoTransformer:
         # ---- temporal VideoTransformerBlock on the same token layout (video_attention.py:125-168) ----
         # rows (b, t, pixel) with pt pixels per frame: all of them, or this rank's pixel range of ALL T frames (one all-to-all in)
         ht, pt = (h, pix) if sp is None else (sp.to_pixels(h, B, T, pix), sp.pix_local(pix))
-        nin, xm = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=self._time_emb(B * T, T), rows_per_vec=pt, want_sum=True)
-        xm = self.t_ff_in(nin, residual=xm, out_f32=st)
+        # x_mix = x + time_pos_embed (video_attention.py:318-321) is never written: norm_in normalises the sum on the fly and ff_in takes x and the per-frame
+        # embedding as residual + row vector (round 6: one fp32 tensor less written and read per block)
+        temb = self._time_emb(B * T, T)
+        nin = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=temb, rows_per_vec=pt)
+        xm = self.t_ff_in(nin, residual=ht, out_f32=st, rowvec=temb, rows_per_vec=pt)
         n1 = ops.layernorm(xm, *self.t_ln["norm1"])
         qkv = ops.gemm(n1, self.t_wqkv)
         at = torch.empty((B * T * pt, c), dtype=e16, device=x.device)

@@ -312,12 +312,14 @@ def _ff_unpack(img, hidden, C, esize, dtype):
     return w1, b1, w2
 
 
-def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None):
+def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None, rowvec=None, rows_per_vec=0):
     if not hasattr(img, "_ff_unpacked"):          # cached ON the image tensor object (an address can be recycled by another layer's image)
         img._ff_unpacked = _ff_unpack(img, hidden, x.shape[1], x.element_size(), x.dtype)
     w1, b1, w2 = img._ff_unpacked
     y = x.float() @ w1.t() + b1
     y = (y[:, :hidden] * F.gelu(y[:, hidden:])) @ w2.t() + b2
+    if rowvec is not None:
+        y = y + rowvec[:, : y.shape[1]].repeat_interleave(rows_per_vec, dim=0)[: y.shape[0]]
     if residual is not None:
         y = y + residual.float()
     if blend is not None:

@@ -151,6 +151,13 @@ def test_ff_geglu_fused(ops, M):
         name = f"ff fused M={M} res={'n' if res is None else res.dtype} blend={blend is not None} out32={out_f32}"
         check(name + " vs two launches", got, two, 1.2e-2, 8e-3 if not out_f32 else 0.0)      # 16-bit output: one flipped output rounding (bf16: 2^-7 relative)
         check(name + " vs fp32 torch", got, ref, 3e-2, 1e-2)
+    # per-frame vector (ABI v9: x + time_pos_embed enters as residual + row vector, video_attention.py:318-321): rows_per_vec = 96, a ragged last group
+    rpv = 96
+    rv = rnd((M + rpv - 1) // rpv, C + 8, seed=50, dtype=torch.float32)[:, :C]
+    got = ops.ff_geglu_fused(x, img, Hd, b2, residual=r32, out_f32=True, rowvec=rv, rows_per_vec=rpv)
+    check(f"ff fused M={M} + per-frame vector vs fp32 torch", got, ff32 + r32 + rv.repeat_interleave(rpv, 0)[:M], 3e-2, 1e-2)
+    base = ops.ff_geglu_fused(x, img, Hd, b2, residual=r32, out_f32=True)
+    check(f"ff fused M={M} + per-frame vector vs (without) + vector", got, base + rv.repeat_interleave(rpv, 0)[:M], 2e-6, 2e-6)
 
 
 @pytest.mark.parametrize("M", [1, 31, 32, 97, 4096, 33000 + 17])
