@@ -300,12 +300,17 @@ int svd_frames_to_uint8(const float* X, uint8_t* Y, int32_t frames, int32_t pix,
  *   b2 [320] fp32.  R: residual rows or NULL; S: blend partner rows or NULL (alpha ignored then); both fp32 when res_f32 else 16 bit.
  *   Y  fp32 rows when out_f32, else 16-bit rows.  The hidden activation is rounded to the 16-bit type exactly like the two-launch path.
  *   rowvec (ABI v9): optional per-frame vector rows (fp32, leading dimension rowvec_ld >= 320) added to the result, row m taking vector m / rows_per_vec
- *      (rows_per_vec % 32 == 0): `x + time_pos_embed` of the time_stack enters as R + rowvec, the sum is never materialised (video_attention.py:318-321). */
+ *      (rows_per_vec % 32 == 0): `x + time_pos_embed` of the time_stack enters as R + rowvec, the sum is never materialised (video_attention.py:318-321).
+ *   Yn (ABI v10): optional second output (16-bit rows, leading dimension ldyn >= 320) = LayerNorm(Y + ln_addvec[m / ln_rows_per_vec]) * ln_gamma + ln_beta,
+ *      the nn.LayerNorm that consumes the block's result (norm_in of the time_stack over x + time_pos_embed behind the spatial ff, norm1 behind ff_in:
+ *      video_attention.py:125-168,318-321); only with an fp32 residual, fp32 output and no blend (SVD_EINVAL otherwise).  ln_addvec may be NULL. */
 int64_t svd_ff_fused_pack_bytes(int32_t hidden);
 int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t channels, int32_t hidden, const float* b2,
                        const void* R, int64_t ldr, const void* S, int64_t lds, float alpha, int32_t res_f32,
                        void* Y, int64_t ldy, int32_t out_f32, int64_t M, int32_t dtype,
-                       const float* rowvec, int32_t rowvec_ld, int32_t rows_per_vec, svd_stream_t stream);
+                       const float* rowvec, int32_t rowvec_ld, int32_t rows_per_vec,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_addvec, int32_t ln_addvec_ld, int32_t ln_rows_per_vec,
+                       svd_bf16* Yn, int64_t ldyn, svd_stream_t stream);
 
 /* Row-owning 320 -> 320 projection of the fp32 residual stream, optionally with the LayerNorm that follows it (ABI v9, round 6):
  *     V  = R + bias + rowvec[row / rows_per_vec] + X . W^T                  -> Y  (fp32 rows when out_f32, else 16-bit rows; may be NULL when Yn is given)

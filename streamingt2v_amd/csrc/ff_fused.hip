@@ -57,12 +57,17 @@ constexpr int FF_LDS_TOTAL = FF_LDS_B2 + FF_C * 4;             // 126 208 B
 // Epilogue of both forms (round 6): acc[o][r] = O[row rbase + (r & 3) + 8 (r >> 2)][channel ch0 + 32 o] of this lane; + b2 (LDS, bl[32 o]), + residual, blend, store.
 // One dword (or 16-bit) access per register: 2 token rows x 128 (64) contiguous bytes per instruction.  The residual (and blend partner) loads of 4 accumulator
 // registers x NO tiles are issued together before their first use (the S^T accumulators and fragment rings are dead here).
-template <class E, int RES, bool OUT32, bool BLEND, int NO>
-__device__ __forceinline__ void ff_epilogue(const f32x16_t (&acc)[NO], int rbase, int M, int ch0, const float* bl, const float* rv, const void* __restrict__ R,
-                                            int64_t ldr, const void* __restrict__ S, int64_t lds, float alpha, void* __restrict__ Y, int64_t ldy) {
-    float bias[NO];          // b2 + the per-frame vector of this wave's 32 rows (rv: already at the frame's row and this lane's channel; NULL = none)
+// LN: also Yn = LayerNorm(V + addvec[frame]) * gamma + beta in the 16-bit type (the nn.LayerNorm that consumes the block's result: norm_in of the time_stack with
+// x + time_pos_embed, norm1 behind ff_in; video_attention.py:125-168,318-321): the 32 lanes of a half-wave hold the same 16 tokens, so the statistics are a 32-lane
+// butterfly per token over this wave's NO x 32 channels; in the eight-wave form (PAIRX) the two waves of a pair hold one half of a token's 320 channels each and merge
+// (mean, M2) of their halves through LDS (Chan's parallel update: exact, one exchange, one workgroup barrier).
+struct FfLn { const float* gamma; const float* beta; float eps; const float* addvec; svd_bf16* Yn; int64_t ldyn; float* xch_own; const float* xch_other; };
+template <class E, int RES, bool OUT32, bool BLEND, int NO, bool LN, bool PAIRX>
+__device__ __forceinline__ void ff_epilogue(f32x16_t (&acc)[NO], int rbase, int M, int ch0, int l31, int hi, const float* bl, const float* vecp, const void* __restrict__ R,
+                                            int64_t ldr, const void* __restrict__ S, int64_t lds, float alpha, void* __restrict__ Y, int64_t ldy, const FfLn& ln) {
+    float bias[NO];          // b2 + the per-frame vector of this wave's 32 rows (vecp: already at the frame's row and this lane's channel; NULL = none)
 #pragma unroll
-    for (int o = 0; o < NO; ++o) bias[o] = bl[32 * o] + (rv ? rv[32 * o] : 0.f);
+    for (int o = 0; o < NO; ++o) bias[o] = bl[32 * o] + (vecp ? vecp[32 * o] : 0.f);
     constexpr int G = 4;                                       // registers (token rows) per batch
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += G) {
@@ -104,9 +109,65 @@ __device__ __forceinline__ void ff_epilogue(const f32x16_t (&acc)[NO], int rbase
                 if constexpr (BLEND) v = alpha * sv[g][o] + (1.0f - alpha) * v;
                 if constexpr (OUT32) ((float*)Y)[trow[g] * ldy + ch0 + 32 * o] = v;
                 else ((svd_bf16*)Y)[trow[g] * ldy + ch0 + 32 * o] = E::from_f32(v);
+                if constexpr (LN) acc[o][r] = v;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (LN) {
+        float gam[NO], bet[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            gam[o] = ln.gamma[ch0 + 32 * o]; bet[o] = ln.beta[ch0 + 32 * o];
+            const float a = ln.addvec ? ln.addvec[32 * o] : 0.f;          // addvec: already at the frame's row and this lane's channel
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[o][r] += a;
+        }
+        constexpr float inv_w = 1.f / (float)(32 * NO);
+        float mean[16], m2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sm = 0.f;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) sm += acc[o][r];
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) sm += __shfl_xor(sm, m, 64);
+            mean[r] = sm * inv_w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sq = 0.f;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) { const float d = acc[o][r] - mean[r]; sq += d * d; }
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) sq += __shfl_xor(sq, m, 64);
+            m2[r] = sq;
+        }
+        if constexpr (PAIRX) {
+            if (l31 == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) *(float4*)(ln.xch_own + hi * 32 + 2 * r) = make_float4(mean[r], m2[r], mean[r + 1], m2[r + 1]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float4 p = *(const float4*)(ln.xch_other + hi * 32 + 2 * r);
+                const float d0 = mean[r] - p.x, d1 = mean[r + 1] - p.z;
+                m2[r] += p.y + (float)(16 * NO) * d0 * d0;          // n_a n_b / (n_a + n_b) = (32 NO)^2 / (64 NO)
+                m2[r + 1] += p.w + (float)(16 * NO) * d1 * d1;
+                mean[r] = 0.5f * (mean[r] + p.x);
+                mean[r + 1] = 0.5f * (mean[r + 1] + p.z);
+            }
+        }
+        constexpr float inv_c = 1.f / (float)FF_C;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float rstd = rsqrtf(m2[r] * inv_c + ln.eps);
+            const int t = rbase + (r & 3) + 8 * (r >> 2);
+            svd_bf16* np = ln.Yn + (int64_t)(t < M ? t : M - 1) * ln.ldyn + ch0;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) np[32 * o] = E::from_f32((acc[o][r] - mean[r]) * rstd * gam[o] + bet[o]);
+        }
     }
 }
 
@@ -114,12 +175,15 @@ __device__ __forceinline__ void ff_epilogue(const f32x16_t (&acc)[NO], int rbase
 // BLEND: Y = alpha * S + (1 - alpha) * (...) with S of the residual's type (the temporal block's AlphaBlender, video_attention.py:318-322)
 // PV (probe builds only, -DSVD_FF_PROBES; results are WRONG for PV != 0): 1 = no LDS-DMA in the steps (stale weights), 2 = no GELU arithmetic,
 // 3 = neither, 4 = no MFMA of S^T (phase A: reads + GELU + DMA only)
-template <class E, int RES, bool OUT32, bool BLEND = false, int PV = 0>
+template <class E, int RES, bool OUT32, bool BLEND = false, int PV = 0, bool LN = false>
 __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp, int nch,
                                                                 const float* __restrict__ b2, const void* __restrict__ R, int64_t ldr,
                                                                 const void* __restrict__ S, int64_t lds, float alpha,
                                                                 void* __restrict__ Y, int64_t ldy, int M, int ntiles,
-                                                                const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec) {
+                                                                const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec,
+                                                                const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps,
+                                                                const float* __restrict__ ln_addvec, int ln_addvec_ld, int ln_rows_per_vec,
+                                                                svd_bf16* __restrict__ Yn, int64_t ldyn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ff_start_delay();
     const uint32_t sbase = lds_addr_of(smem);
@@ -331,7 +395,9 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
             // rows_per_vec % 32 == 0: one vector per wave; a wave wholly past M recomputes row M - 1 and must take ITS vector (its stores are duplicates of that row)
             const int vrow = tile * 128 + wave * 32 < M ? tile * 128 + wave * 32 : M - 1;
             const float* rv = rowvec ? rowvec + (int64_t)(vrow / rows_per_vec) * rowvec_ld + l31 : nullptr;
-            ff_epilogue<E, RES, OUT32, BLEND, FF_NO>(o_acc, rbase, M, l31, bl, rv, R, ldr, S, lds, alpha, Y, ldy);
+            FfLn ln{};
+            if constexpr (LN) ln = FfLn{ln_gamma, ln_beta, ln_eps, ln_addvec ? ln_addvec + (int64_t)(vrow / ln_rows_per_vec) * ln_addvec_ld + l31 : nullptr, Yn, ldyn, nullptr, nullptr};
+            ff_epilogue<E, RES, OUT32, BLEND, FF_NO, LN, false>(o_acc, rbase, M, l31, l31, hi, bl, rv, R, ldr, S, lds, alpha, Y, ldy, ln);
         }
     }
     svd_wait_dma();          // the ring's last requests (chunks of a tile that does not exist) must not outlive the workgroup's LDS
@@ -359,12 +425,15 @@ constexpr int F8_NO = FF_NO / 2;                               // 5 output tiles
 
 // PV (probe builds only; results are WRONG for PV != 0; bit mask): 1 = no LDS-DMA in the steps, 2 = no GELU arithmetic, 4 = no workgroup barrier in the steps,
 // 8 = no fragment reads in the steps (stale registers), 16 = fragments 7 MFMAs ahead (ring of 8) instead of 3
-template <class E, int RES, bool OUT32, bool BLEND = false, int PV = 0>
+template <class E, int RES, bool OUT32, bool BLEND = false, int PV = 0, bool LN = false>
 __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp, int nch,
                                                                  const float* __restrict__ b2, const void* __restrict__ R, int64_t ldr,
                                                                  const void* __restrict__ S, int64_t lds, float alpha,
                                                                  void* __restrict__ Y, int64_t ldy, int M, int ntiles,
-                                                                 const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec) {
+                                                                 const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec,
+                                                                 const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps,
+                                                                 const float* __restrict__ ln_addvec, int ln_addvec_ld, int ln_rows_per_vec,
+                                                                 svd_bf16* __restrict__ Yn, int64_t ldyn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t sbase = lds_addr_of(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -548,7 +617,12 @@ __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16*
             const float* bl = (const float*)(smem + FF_LDS_B2) + 160 * q + l31;
             const int vrow = tile * 128 + pair * 32 < M ? tile * 128 + pair * 32 : M - 1;          // (see the four-wave kernel)
             const float* rv = rowvec ? rowvec + (int64_t)(vrow / rows_per_vec) * rowvec_ld + 160 * q + l31 : nullptr;
-            ff_epilogue<E, RES, OUT32, BLEND, F8_NO>(o_acc, rbase, M, 160 * q + l31, bl, rv, R, ldr, S, lds, alpha, Y, ldy);
+            FfLn ln{};
+            // (mean, M2) exchange inside the wave pair: the step-parity-0 GEGLU exchange slots of the two waves are dead here -- every wave has passed the last step's
+            // barrier -- and are next written after the next tile's first barrier
+            if constexpr (LN) ln = FfLn{ln_gamma, ln_beta, ln_eps, ln_addvec ? ln_addvec + (int64_t)(vrow / ln_rows_per_vec) * ln_addvec_ld + 160 * q + l31 : nullptr, Yn, ldyn,
+                                        (float*)(smem + F8_LDS_X + (wave << 10)), (const float*)(smem + F8_LDS_X + ((wave ^ 1) << 10))};
+            ff_epilogue<E, RES, OUT32, BLEND, F8_NO, LN, true>(o_acc, rbase, M, 160 * q + l31, l31, hi, bl, rv, R, ldr, S, lds, alpha, Y, ldy, ln);
         }
     }
     svd_wait_dma();
@@ -568,8 +642,13 @@ extern "C" { int svd_ff_probe_variant = 0; }      // 1..4 / 101..116: timing pro
 #endif
 extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t channels, int32_t hidden, const float* b2, const void* R,
                                   int64_t ldr, const void* S, int64_t lds, float alpha, int32_t res_f32, void* Y, int64_t ldy, int32_t out_f32, int64_t M,
-                                  int32_t dtype, const float* rowvec, int32_t rowvec_ld, int32_t rows_per_vec, svd_stream_t stream) {
+                                  int32_t dtype, const float* rowvec, int32_t rowvec_ld, int32_t rows_per_vec, const float* ln_gamma, const float* ln_beta,
+                                  float ln_eps, const float* ln_addvec, int32_t ln_addvec_ld, int32_t ln_rows_per_vec, svd_bf16* Yn, int64_t ldyn,
+                                  svd_stream_t stream) {
     if (rowvec && (rows_per_vec <= 0 || rows_per_vec % 32 || rowvec_ld < FF_C)) return SVD_EINVAL;
+    // the fused LayerNorm exists for the fp32-stream form (fp32 residual in, fp32 rows out, no blend): the two places a LayerNorm consumes a feed-forward's result
+    if (Yn && (!ln_gamma || !ln_beta || !R || !res_f32 || !out_f32 || S || ldyn < FF_C)) return SVD_EINVAL;
+    if (Yn && ln_addvec && (ln_rows_per_vec <= 0 || ln_rows_per_vec % 32 || ln_addvec_ld < FF_C)) return SVD_EINVAL;
     if (!X || !Wp || !b2 || !Y || M <= 0 || M > 0x7fffff00 || channels != FF_C || hidden <= 0 || hidden % 64) return SVD_EINVAL;
     if (ldx % 8 || ldx < FF_C || ldy < FF_C || (R && ldr < FF_C)) return SVD_EINVAL;
     if (((uintptr_t)X | (uintptr_t)Wp) & 15) return SVD_EINVAL;
@@ -595,12 +674,13 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
     // frames/s); with the batched epilogue the eight-wave form is ahead (1.24 vs 1.31 ms; same-box stage-1 line 2.336 vs 2.318, AR chunk 7.48 vs 7.53 s:
     // profiles/r05_ff_fused_probe_epilogue_mlp.txt, r05_bench6_ff_waves_ab.txt) and is the default.
     static const bool four_waves = [] { const char* e = getenv("SVD_FF_WAVES"); return e && e[0] == '4'; }();
-#define FF_LAUNCH(RES, OUT)  FF_LAUNCH2(RES, OUT, false)
-#define FF_LAUNCH2(RES, OUT, BL)                                                                                                            \
+#define FF_LAUNCH(RES, OUT)  FF_LAUNCH3(RES, OUT, false, false)
+#define FF_LAUNCH2(RES, OUT, BL)  FF_LAUNCH3(RES, OUT, BL, false)
+#define FF_LAUNCH3(RES, OUT, BL, LNV)                                                                                                       \
     do {                                                                                                                                 \
         SVD_DISPATCH_DTYPE(dtype, {                                                                                                      \
             if (four_waves FF_FORCE4) {          /* probe builds: the variant alone decides */                                                                                                  \
-                auto kern = ff_geglu_fused_kernel<E, RES, OUT, BL>;                                                                       \
+                auto kern = ff_geglu_fused_kernel<E, RES, OUT, BL, 0, LNV>;                                                                       \
                 static unsigned char attr_set_dev[64] = {0};                                                                             \
                 unsigned char& attr_set = attr_set_dev[dev];                                                                             \
                 if (!attr_set) {                                                                                                         \
@@ -608,9 +688,9 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
                     attr_set = true;                                                                                                     \
                 }                                                                                                                        \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
-                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec);                                                                                      \
+                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn);                                                                                      \
             } else {                                                                                                                     \
-                auto kern = ff_geglu_fused8_kernel<E, RES, OUT, BL>;                                                                      \
+                auto kern = ff_geglu_fused8_kernel<E, RES, OUT, BL, 0, LNV>;                                                                      \
                 static unsigned char attr_set_dev[64] = {0};                                                                             \
                 unsigned char& attr_set = attr_set_dev[dev];                                                                             \
                 if (!attr_set) {                                                                                                         \
@@ -618,7 +698,7 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
                     attr_set = true;                                                                                                     \
                 }                                                                                                                        \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
-                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec);                                                                                      \
+                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn);                                                                                      \
             }                                                                                                                            \
         });                                                                                                                              \
     } while (0)
@@ -628,13 +708,13 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
         do {                                                                                                                             \
             auto kern = ff_geglu_fused_kernel<ElemF16, 2, true, false, PVV>;                                                                   \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn); \
         } while (0)
 #define FF_PROBE8(PVV)                                                                                                                   \
         do {                                                                                                                             \
             auto kern = ff_geglu_fused8_kernel<ElemF16, 2, true, false, PVV>;                                                              \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn); \
         } while (0)
         switch (svd_ff_probe_variant) {
             case 1: FF_PROBE(1); break; case 2: FF_PROBE(2); break; case 3: FF_PROBE(3); break; case 4: FF_PROBE(4); break;
@@ -647,7 +727,9 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
     }
 #endif
     const int res = R ? (res_f32 ? 2 : 1) : 0;
-    if (S) {
+    if (Yn) {
+        FF_LAUNCH3(2, true, false, true);
+    } else if (S) {
         if (res == 2) { if (out_f32) FF_LAUNCH2(2, true, true); else FF_LAUNCH2(2, false, true); }
         else { if (out_f32) FF_LAUNCH2(1, true, true); else FF_LAUNCH2(1, false, true); }
     } else if (res == 2) { if (out_f32) FF_LAUNCH(2, true); else FF_LAUNCH(2, false); }
@@ -655,6 +737,7 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
     else { if (out_f32) FF_LAUNCH(0, true); else FF_LAUNCH(0, false); }
 #undef FF_LAUNCH
 #undef FF_LAUNCH2
+#undef FF_LAUNCH3
     SVD_CHECK_LAUNCH("ff_geglu_fused");
     return SVD_OK;
 }

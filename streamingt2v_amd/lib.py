@@ -30,7 +30,7 @@ def _lib_file():
 
 LIB_PATH = os.path.join(_HERE, _lib_file())
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
@@ -135,7 +135,8 @@ def _load():
     lib.svd_gelu_rows.argtypes = [vp, i64, i64, i32, i32, vp]
     lib.svd_ff_fused_pack_bytes.restype = C.c_int64
     lib.svd_ff_fused_pack_bytes.argtypes = [i32]
-    lib.svd_ff_geglu_fused.argtypes = [vp, i64, vp, i32, i32, vp, vp, i64, vp, i64, f32, i32, vp, i64, i32, i64, i32, vp, i32, i32, vp]
+    lib.svd_ff_geglu_fused.argtypes = [vp, i64, vp, i32, i32, vp, vp, i64, vp, i64, f32, i32, vp, i64, i32, i64, i32, vp, i32, i32,
+                                       vp, vp, f32, vp, i32, i32, vp, i64, vp]
     lib.svd_rowgemm320_pack_bytes.restype = C.c_int64
     lib.svd_rowgemm320_pack_bytes.argtypes = []
     lib.svd_rowgemm320.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, i64, vp, i64, i32, vp, vp, f32, vp, i64, i64, i32, vp]

@@ -365,15 +365,18 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
 # FUSED FEED-FORWARD (round 5, csrc/ff_fused.hip): LayerNorm output -> GEGLU projection -> gate -> down-projection (+ residual, + blend) in ONE
 # launch for the 320-channel blocks; the [M, 1280] hidden activation never reaches HBM.  SVD_FF_FUSED=0 keeps the two svd_gemm launches (A/B).
 FF_FUSED = _os.environ.get("SVD_FF_FUSED", "1") != "0"
+FF_FUSED_LN = _os.environ.get("SVD_FF_FUSED_LN", "1") != "0"      # (A/B) the LayerNorm behind a feed-forward from the fused kernel's epilogue (round 6)
 
 
 def ff_fused_ok(channels, hidden):
     return FF_FUSED and channels == 320 and hidden % 64 == 0
 
 
-def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None, rowvec=None, rows_per_vec=0):
+def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None, rowvec=None, rows_per_vec=0, ln=None, ln_eps=1e-5, ln_addvec=None,
+                   ln_rows_per_vec=0):
     """x [M, 320] 16-bit rows; img = video_model.pack_ff_fused(...) on the device (uint8); b2 [320] fp32; residual [M, 320] (16 bit or fp32);
-    blend = (alpha, S) like ops.gemm.  Returns residual + b2 + W2 (value * gelu(gate)) [blended], fp32 when out_f32 else 16 bit."""
+    blend = (alpha, S) like ops.gemm.  Returns residual + b2 + W2 (value * gelu(gate)) [blended], fp32 when out_f32 else 16 bit.
+    ln = (gamma, beta) fp32 [320]: also returns LayerNorm(result + ln_addvec[row // ln_rows_per_vec]) in the 16-bit type -> (y, yn); fp32 residual and output only."""
     assert x.dtype in (BF16, F16) and x.is_cuda and x.stride(1) == 1 and x.shape[1] == 320 and img.dtype == torch.uint8
     M, Cc = x.shape
     r32 = None
@@ -389,20 +392,30 @@ def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=Fal
         out = torch.empty((M, Cc), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     assert out.shape == (M, Cc) and out.stride(1) == 1 and out.dtype in (torch.float32, x.dtype)
     flops = 2.0 * M * (2 * hidden) * Cc + 2.0 * M * hidden * Cc
-    nbytes = float(M * Cc * (2 + out.element_size() + (R.element_size() if R is not None else 0) + (S.element_size() if S is not None else 0)) + img.numel())
+    nbytes = float(M * Cc * (2 + out.element_size() + (R.element_size() if R is not None else 0) + (S.element_size() if S is not None else 0) + (2 if ln is not None else 0))
+                   + img.numel())
     if worklog is not None:
         _wl("ff_geglu_fused_kernel", flops, nbytes)
-    args = (_p(x), x.stride(0), _p(img), Cc, hidden, _p(b2), _p(R), R.stride(0) if R is not None else 0, _p(S), S.stride(0) if S is not None else 0,
-            float(alpha), int(bool(r32)), _p(out), out.stride(0), int(out.dtype == torch.float32), M, _dt(x),
-            _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_vec, _stream())
+    yn = g = b = None
+    if ln is not None:
+        g, b = ln
+        assert r32 and out.dtype == torch.float32 and S is None and g.dtype == b.dtype == torch.float32 and g.numel() == b.numel() == Cc
+        yn = torch.empty((M, Cc), dtype=x.dtype, device=x.device)
+        if ln_addvec is not None:
+            assert ln_addvec.dtype == torch.float32 and ln_addvec.stride(-1) == 1 and ln_rows_per_vec > 0 and ln_rows_per_vec % 32 == 0
     if rowvec is not None:
         assert rowvec.dtype == torch.float32 and rowvec.stride(-1) == 1 and rows_per_vec > 0 and rows_per_vec % 32 == 0
+    args = (_p(x), x.stride(0), _p(img), Cc, hidden, _p(b2), _p(R), R.stride(0) if R is not None else 0, _p(S), S.stride(0) if S is not None else 0,
+            float(alpha), int(bool(r32)), _p(out), out.stride(0), int(out.dtype == torch.float32), M, _dt(x),
+            _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_vec,
+            _p(g), _p(b), float(ln_eps), _p(ln_addvec if ln is not None else None), ln_addvec.stride(0) if (ln is not None and ln_addvec is not None) else 0,
+            ln_rows_per_vec if ln is not None else 0, _p(yn), Cc if yn is not None else 0, _stream())
     if trace is not None:
-        with trace.launch("ff_fused_c320", flops=flops, sig=f"ff_M{M}_C{Cc}_H{hidden}_r{int(bool(r32)) if R is not None else 'n'}_o{int(out.dtype == torch.float32)}", nbytes=nbytes):
+        with trace.launch("ff_fused_c320", flops=flops, sig=f"ff_M{M}_C{Cc}_H{hidden}_r{int(bool(r32)) if R is not None else 'n'}_o{int(out.dtype == torch.float32)}{'_ln' if ln is not None else ''}", nbytes=nbytes):
             check(_lib.svd_ff_geglu_fused(*args), "svd_ff_geglu_fused")
-        return out
+        return out if ln is None else (out, yn)
     check(_lib.svd_ff_geglu_fused(*args), "svd_ff_geglu_fused")
-    return out
+    return out if ln is None else (out, yn)
 
 
 # ROW-OWNING 320 -> 320 PROJECTION (round 6, csrc/rowgemm.hip): proj_in / attn1.to_out / proj_out of the 320-channel transformer blocks in ONE launch with the

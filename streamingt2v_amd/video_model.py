@@ -140,15 +140,26 @@ class FeedForward:
         self.img = pack_ff_fused(w1r, b1r, w2r).to(dev) if ops.ff_fused_ok(self.c, self.hidden) else None
         self.img_dtype = ops.ELEM          # the packed image is an opaque byte blob in THIS element type: the kernel must be launched with the same one
 
-    def __call__(self, x, residual=None, out_f32=False, blend=None, rowvec=None, rows_per_vec=0):
-        """rowvec / rows_per_vec: a per-frame vector added to the result (residual + rowvec + ff(x)): `x + time_pos_embed` without materialising the sum."""
-        if self.img is not None and ops.FF_FUSED and (rowvec is None or rows_per_vec % 32 == 0):
+    def __call__(self, x, residual=None, out_f32=False, blend=None, rowvec=None, rows_per_vec=0, ln=None, ln_addvec=None, ln_rows_per_vec=0):
+        """rowvec / rows_per_vec: a per-frame vector added to the result (residual + rowvec + ff(x)): `x + time_pos_embed` without materialising the sum.
+        ln = (gamma, beta): the LayerNorm that consumes the result, over result + ln_addvec[row // ln_rows_per_vec] -> returns (y, LayerNorm(...)); the fused
+        kernel emits it from its accumulators where it can (fp32 stream), else svd_layernorm follows."""
+        fused = self.img is not None and ops.FF_FUSED and (rowvec is None or rows_per_vec % 32 == 0)
+        if fused:
             if x.dtype != self.img_dtype:
                 raise TypeError(f"fused feed-forward weights were packed as {self.img_dtype} (ops.ELEM at load_state_dict) but the activations are {x.dtype}: "
                                 f"call ops.set_element_dtype BEFORE load_state_dict")
-            return ops.ff_geglu_fused(x, self.img, self.hidden, self.b2, residual=residual, blend=blend, out_f32=out_f32, rowvec=rowvec, rows_per_vec=rows_per_vec)
-        g = ops.gemm(x, self.w1, bias=self.b1, geglu=True)
-        return ops.gemm(g, self.w2, bias=self.b2, rowvec=rowvec, rows_per_vec=rows_per_vec, residual=residual, blend=blend, out_f32=out_f32)
+            if (ln is not None and ops.FF_FUSED_LN and out_f32 and blend is None and residual is not None and residual.dtype == torch.float32
+                    and (ln_addvec is None or ln_rows_per_vec % 32 == 0)):
+                return ops.ff_geglu_fused(x, self.img, self.hidden, self.b2, residual=residual, out_f32=True, rowvec=rowvec, rows_per_vec=rows_per_vec,
+                                          ln=ln, ln_addvec=ln_addvec, ln_rows_per_vec=ln_rows_per_vec)
+            y = ops.ff_geglu_fused(x, self.img, self.hidden, self.b2, residual=residual, blend=blend, out_f32=out_f32, rowvec=rowvec, rows_per_vec=rows_per_vec)
+        else:
+            g = ops.gemm(x, self.w1, bias=self.b1, geglu=True)
+            y = ops.gemm(g, self.w2, bias=self.b2, rowvec=rowvec, rows_per_vec=rows_per_vec, residual=residual, blend=blend, out_f32=out_f32)
+        if ln is None:
+            return y
+        return y, ops.layernorm(y, *ln, addvec=ln_addvec, rows_per_vec=ln_rows_per_vec)
 
 
 def pack_x3(w2d, taps):
@@ -474,16 +485,22 @@ class SpatialVideoTransformer:
         else:
             h = ops.gemm(a, self.s_wo, bias=self.s_bo, rowvec=v2, rows_per_vec=pix, residual=h, out_f32=st)
             n3 = ops.layernorm(h, *self.s_ln["norm3"])
-        h = self.s_ff(n3, residual=h, out_f32=st)                                     # x_spatial
+        # round 6: the two LayerNorms that consume a feed-forward's result (norm_in over x_spatial + time_pos_embed, norm1 behind ff_in) come out of the
+        # fused feed-forward's own epilogue where the fp32 stream runs; with `sp` the rows change layout in between and norm_in stays a kernel of its own
+        temb = self._time_emb(B * T, T)
+        nin = None
+        if sp is None:
+            h, nin = self.s_ff(n3, residual=h, out_f32=st, ln=self.t_ln["norm_in"], ln_addvec=temb, ln_rows_per_vec=pix)             # x_spatial
+        else:
+            h = self.s_ff(n3, residual=h, out_f32=st)
         # ---- temporal VideoTransformerBlock on the same token layout (video_attention.py:125-168) ----
         # rows (b, t, pixel) with pt pixels per frame: all of them, or this rank's pixel range of ALL T frames (one all-to-all in)
         ht, pt = (h, pix) if sp is None else (sp.to_pixels(h, B, T, pix), sp.pix_local(pix))
         # x_mix = x + time_pos_embed (video_attention.py:318-321) is never written: norm_in normalises the sum on the fly and ff_in takes x and the per-frame
         # embedding as residual + row vector (round 6: one fp32 tensor less written and read per block)
-        temb = self._time_emb(B * T, T)
-        nin = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=temb, rows_per_vec=pt)
-        xm = self.t_ff_in(nin, residual=ht, out_f32=st, rowvec=temb, rows_per_vec=pt)
-        n1 = ops.layernorm(xm, *self.t_ln["norm1"])
+        if nin is None:
+            nin = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=temb, rows_per_vec=pt)
+        xm, n1 = self.t_ff_in(nin, residual=ht, out_f32=st, rowvec=temb, rows_per_vec=pt, ln=self.t_ln["norm1"])
         qkv = ops.gemm(n1, self.t_wqkv)
         at = torch.empty((B * T * pt, c), dtype=e16, device=x.device)
         ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pt, heads)

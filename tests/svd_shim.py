@@ -312,7 +312,8 @@ def _ff_unpack(img, hidden, C, esize, dtype):
     return w1, b1, w2
 
 
-def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None, rowvec=None, rows_per_vec=0):
+def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=False, out=None, rowvec=None, rows_per_vec=0, ln=None, ln_eps=1e-5, ln_addvec=None,
+                   ln_rows_per_vec=0):
     if not hasattr(img, "_ff_unpacked"):          # cached ON the image tensor object (an address can be recycled by another layer's image)
         img._ff_unpacked = _ff_unpack(img, hidden, x.shape[1], x.element_size(), x.dtype)
     w1, b1, w2 = img._ff_unpacked
@@ -325,6 +326,9 @@ def ff_geglu_fused(x, img, hidden, b2, *, residual=None, blend=None, out_f32=Fal
     if blend is not None:
         alpha, S = blend
         y = alpha * S.float() + (1.0 - alpha) * y
+    if ln is not None:
+        assert out is None and out_f32 and blend is None and residual is not None and residual.dtype == torch.float32
+        return y, layernorm(y, ln[0], ln[1], eps=ln_eps, addvec=ln_addvec, rows_per_vec=ln_rows_per_vec).to(x.dtype)
     if out is not None:
         out.copy_(y.to(out.dtype))
         return out

@@ -158,6 +158,23 @@ def test_ff_geglu_fused(ops, M):
     check(f"ff fused M={M} + per-frame vector vs fp32 torch", got, ff32 + r32 + rv.repeat_interleave(rpv, 0)[:M], 3e-2, 1e-2)
     base = ops.ff_geglu_fused(x, img, Hd, b2, residual=r32, out_f32=True)
     check(f"ff fused M={M} + per-frame vector vs (without) + vector", got, base + rv.repeat_interleave(rpv, 0)[:M], 2e-6, 2e-6)
+    # fused LayerNorm of the result (ABI v10: norm_in over x_spatial + time_pos_embed, norm1 behind ff_in; video_attention.py:125-168,318-321): the fp32 rows
+    # must be bit-identical to the launch without it, the normalised rows equal svd_layernorm of them to one flipped 16-bit rounding
+    lg, lb = rnd(C, seed=51, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=52, dtype=torch.float32) * 0.1
+    av = rnd((M + rpv - 1) // rpv, C + 24, seed=53, dtype=torch.float32)[:, :C]
+    for vec, add in [(None, None), (None, av), (rv, None), (rv, av)]:
+        kw = dict(residual=r32, out_f32=True, rowvec=vec, rows_per_vec=rpv if vec is not None else 0)
+        y, yn = ops.ff_geglu_fused(x, img, Hd, b2, ln=(lg, lb), ln_addvec=add, ln_rows_per_vec=rpv if add is not None else 0, **kw)
+        y0 = ops.ff_geglu_fused(x, img, Hd, b2, **kw)
+        assert torch.equal(y, y0) and yn.dtype == BF16 and yn.shape == (M, C)
+        name = f"ff fused M={M} vec={vec is not None} + LayerNorm(addvec={add is not None})"
+        check(name + " vs svd_layernorm", yn, ops.layernorm(y0, lg, lb, addvec=add, rows_per_vec=rpv if add is not None else 0), 1.2e-2, 8e-3)
+        ref = y0 + (add.repeat_interleave(rpv, 0)[:M] if add is not None else 0)
+        check(name + " vs fp32 torch", yn, F.layer_norm(ref, (C,), lg, lb, 1e-5), 1.2e-2, 8e-3)
+        y2, yn2 = ops.ff_geglu_fused(x, img, Hd, b2, ln=(lg, lb), ln_addvec=add, ln_rows_per_vec=rpv if add is not None else 0, **kw)
+        assert torch.equal(yn, yn2)                      # run to run: no atomics, fixed exchange order
+    with pytest.raises(AssertionError):
+        ops.ff_geglu_fused(x, img, Hd, b2, residual=r16, out_f32=True, ln=(lg, lb))          # the fused LayerNorm exists for the fp32 stream only
 
 
 @pytest.mark.parametrize("M", [1, 31, 32, 97, 4096, 33000 + 17])
