@@ -68,6 +68,15 @@ __device__ __forceinline__ void ff_epilogue(f32x16_t (&acc)[NO], int rbase, int 
     float bias[NO];          // b2 + the per-frame vector of this wave's 32 rows (vecp: already at the frame's row and this lane's channel; NULL = none)
 #pragma unroll
     for (int o = 0; o < NO; ++o) bias[o] = bl[32 * o] + (vecp ? vecp[32 * o] : 0.f);
+    // LN operands: loaded HERE, ahead of the residual loads -- issued behind the Y stores they would wait for every one of them (vmcnt counts in order)
+    float gam[LN ? NO : 1], bet[LN ? NO : 1], av[LN ? NO : 1];
+    if constexpr (LN) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            gam[o] = ln.gamma[ch0 + 32 * o]; bet[o] = ln.beta[ch0 + 32 * o];
+            av[o] = ln.addvec ? ln.addvec[32 * o] : 0.f;          // addvec: already at the frame's row and this lane's channel
+        }
+    }
     constexpr int G = 4;                                       // registers (token rows) per batch
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += G) {
@@ -115,14 +124,10 @@ __device__ __forceinline__ void ff_epilogue(f32x16_t (&acc)[NO], int rbase, int 
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (LN) {
-        float gam[NO], bet[NO];
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            gam[o] = ln.gamma[ch0 + 32 * o]; bet[o] = ln.beta[ch0 + 32 * o];
-            const float a = ln.addvec ? ln.addvec[32 * o] : 0.f;          // addvec: already at the frame's row and this lane's channel
+        for (int o = 0; o < NO; ++o)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[o][r] += a;
-        }
+            for (int r = 0; r < 16; ++r) acc[o][r] += av[o];
         constexpr float inv_w = 1.f / (float)(32 * NO);
         float mean[16], m2[16];
 #pragma unroll
@@ -130,18 +135,14 @@ __device__ __forceinline__ void ff_epilogue(f32x16_t (&acc)[NO], int rbase, int 
             float sm = 0.f;
 #pragma unroll
             for (int o = 0; o < NO; ++o) sm += acc[o][r];
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) sm += __shfl_xor(sm, m, 64);
-            mean[r] = sm * inv_w;
+            mean[r] = half_wave_sum(sm) * inv_w;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float sq = 0.f;
 #pragma unroll
             for (int o = 0; o < NO; ++o) { const float d = acc[o][r] - mean[r]; sq += d * d; }
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) sq += __shfl_xor(sq, m, 64);
-            m2[r] = sq;
+            m2[r] = half_wave_sum(sq);
         }
         if constexpr (PAIRX) {
             if (l31 == 0) {

@@ -181,18 +181,14 @@ __global__ __launch_bounds__(256, 1) void rowgemm320_kernel(const svd_bf16* __re
                 float sm = 0.f;
 #pragma unroll
                 for (int o = 0; o < RG_NO; ++o) sm += acc[o][r];
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1) sm += __shfl_xor(sm, m, 64);        // the 32 lanes of a half-wave hold the same 16 tokens
-                mean[r] = sm * invc;
+                mean[r] = half_wave_sum(sm) * invc;        // the 32 lanes of a half-wave hold the same 16 tokens
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float sq = 0.f;
 #pragma unroll
                 for (int o = 0; o < RG_NO; ++o) { const float d = acc[o][r] - mean[r]; sq += d * d; }
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1) sq += __shfl_xor(sq, m, 64);
-                rstd[r] = rsqrtf(sq * invc + eps);
+                rstd[r] = rsqrtf(half_wave_sum(sq) * invc + eps);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -65,6 +65,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the 32 lanes of this lane's half-wave, the result in every lane.  Four of the five butterfly levels are DPP operands of the add (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror: after each level the lanes a mirror pairs up hold equal partial sums, so a mirror IS the xor) -- VALU rate, no LDS crossbar, no
+// lgkmcnt wait; only the exchange between the two 16-lane rows goes through ds_bpermute.  (Round 6: the LayerNorm epilogues of rowgemm320 / ff_geglu_fused reduce
+// 32 values per 32-row tile this way.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += dpp_mov_f32<0xB1>(v);           // quad_perm [1,0,3,2]
+    v += dpp_mov_f32<0x4E>(v);           // quad_perm [2,3,0,1]
+    v += dpp_mov_f32<0x141>(v);          // row_half_mirror
+    v += dpp_mov_f32<0x140>(v);          // row_mirror
+    return v + __shfl_xor(v, 16, 64);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

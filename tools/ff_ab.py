@@ -11,7 +11,20 @@ for M in (460800, 129024, 1094400):
     x = torch.randn(M, C, device="cuda").to(ops.ELEM)
     r = torch.randn(M, C, device="cuda")
     s_ = torch.randn(M, C, device="cuda")
-    for name, kw in (("fp32 residual -> fp32", dict(residual=r, out_f32=True)), ("fp32 residual + blend -> 16 bit", dict(residual=r, blend=(0.3, s_), out_f32=False))):
+    g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    te = torch.randn((M + 9215) // 9216, C, device="cuda")
+    y0 = torch.randn(M, C, device="cuda")
+    for _ in range(3):
+        ops.layernorm(y0, g, b, addvec=te, rows_per_vec=9216)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.layernorm(y0, g, b, addvec=te, rows_per_vec=9216)
+    e1.record(); torch.cuda.synchronize()
+    print(f"M={M:8d} {'svd_layernorm fp32 -> 16 bit (+vec)':34s} {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+    for name, kw in (("fp32 residual -> fp32", dict(residual=r, out_f32=True)), ("fp32 residual -> fp32 + LayerNorm", dict(residual=r, out_f32=True, ln=(g, b), ln_addvec=te, ln_rows_per_vec=9216)),
+                     ("fp32 residual + blend -> 16 bit", dict(residual=r, blend=(0.3, s_), out_f32=False))):
         for _ in range(3):
             ops.ff_geglu_fused(x, img, Hd, b2, **kw)
         torch.cuda.synchronize()
