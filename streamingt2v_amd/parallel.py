@@ -257,6 +257,7 @@ class JobPlan:
         self.cfg_exchange, self.sp, self.n_videos, self.video_id = None, None, 1, 0
         self.decode_group = None
         self.fallback_reason = None
+        self.abort_report = None          # set when a preflight collective hung: what happened to the data-path communicators
         if world == 1:
             return
         if mode == "job":
@@ -335,9 +336,45 @@ class JobPlan:
             failed, any_hung, err = True, True, err or f"control plane: {type(e).__name__}: {e}"
         if any_hung:
             _CONTROL["use"] = True
+            self.abort_report = self._abort_data_path()
         if not failed:
             return None
         return "job-plan collective preflight failed on " + (f"this rank: {err}" if err else "another rank")
+
+    def _data_path_groups(self):
+        gs = [dist.group.WORLD]
+        for holder in (self.cfg_exchange, self.sp):
+            g = getattr(holder, "group", None)
+            if g is not None and g not in gs:
+                gs.append(g)
+        if self.decode_group is not None and self.decode_group not in gs:
+            gs.append(self.decode_group)
+        return gs
+
+    def _abort_data_path(self, timeout_s=20.0):
+        """After a collective of the plan hung.  What is recoverable: a HOST-side hang (bootstrap, a rank that never arrives: the helper thread stays parked, nothing
+        runs on the device) needs nothing more -- the replicas run on, barrier and max-over-ranks on the gloo control group.  A DEVICE-side hang (a collective kernel
+        spinning on a peer) would block the bench's device-wide torch.cuda.synchronize() for good: the RCCL communicators of the data-path groups are aborted here
+        (ProcessGroupNCCL.abort = ncclCommAbort, which ends such a kernel), on a helper thread joined with a timeout because the abort itself can block.  Returns a
+        short report; if the abort does not come back the bench line may not be produced (the backend's watchdog ends the process) -- INTEGRATION.md says so."""
+        import threading
+        if not torch.cuda.is_available():
+            return "no device: host-side hang, nothing to abort"
+        done = []
+
+        def body():
+            for g in self._data_path_groups():
+                try:
+                    if dist.get_backend(g) != "nccl":
+                        continue
+                    g._get_backend(torch.device("cuda")).abort()
+                    done.append("aborted")
+                except Exception as e:              # noqa: BLE001 -- reported, never raised: the replicas must still run
+                    done.append(f"{type(e).__name__}: {e}")
+        th = threading.Thread(target=body, daemon=True, name="svd-abort")
+        th.start()
+        th.join(timeout_s)
+        return ("abort timed out; " if th.is_alive() else "") + (", ".join(done) if done else "no RCCL communicator")
 
     def _preflight_body(self, dev, errs):
         # Every rank issues EVERY collective of the sequence, in the same order, whatever its local checks say: a rank that stopped at a failed
@@ -410,6 +447,8 @@ class JobPlan:
             return "single GPU"
         if self.mode == "replica":
             why = f"; fell back from the one-job plan: {self.fallback_reason}" if self.fallback_reason else ""
+            if self.abort_report:
+                why += f" [data-path communicators: {self.abort_report}]"
             return f"replica-per-gpu x{self.world} (independent videos, no data-path collective{why})"
         if self.mode == "pairs":
             return (f"{self.n_videos} independent video(s), each on a CFG pair of GPUs (ranks 2k | 2k+1 evaluate the unconditional | conditional half; "

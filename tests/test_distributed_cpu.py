@@ -279,6 +279,7 @@ def _hang_worker(rank, world, port, out):
     parallel.CfgPairExchange.gather = real
     parallel.barrier()                                  # must not touch the hung default group
     slowest = parallel.max_over_ranks(float(rank + 1))
+    assert plan.abort_report is not None and "host-side" in plan.abort_report          # no device here: nothing to abort, and said so
     out.put((rank, plan.mode, plan.fallback_reason, plan.n_videos, plan.video_id, parallel._CONTROL["use"], slowest, dt))
     out.close(); out.join_thread()
     os._exit(0)                                         # the helper threads are parked inside the dead collective: no orderly teardown
