@@ -133,6 +133,13 @@ def precision_plan():
             "decoder_exact_rim": bool(ops.AE_EXACT_RIM), "decoder_stream_fp32_min_channels": int(ops.AE_STREAM_F32_MIN_CH)}
 
 
+def kernel_switches():
+    """The A/B switches of the kernel path (environment overrides in streamingt2v_amd.ops): an A/B line says which side it is."""
+    from streamingt2v_amd import ops
+    return {"ff_fused": bool(ops.FF_FUSED), "ff_fused_layernorm": bool(ops.FF_FUSED_LN), "rowgemm320": bool(ops.ROWGEMM),
+            "zero_copy_concat": bool(ops.ZERO_COPY_CONCAT), "zero_copy_generic": bool(ops.ZERO_COPY_GENERIC)}
+
+
 def build_models(workload, device):
     from streamingt2v_amd.params import init_by_name
     from streamingt2v_amd.temporal_ae import AutoencodingEngineDecoder, VideoDecoder
@@ -556,7 +563,7 @@ def run_stage1(args, rank, world, device):
                        "chunks_timed": [len(per_type[0]), len(per_type[1])], "timed_region_starts_at": "chunk 0 (video boundary)",
                        "frames_kept_per_chunk": list(Stage1Stream.KEPT), "frames_in_timed_steps": kept, "kept_frames_over_time": round(kept_rate, 4),
                        "latent": [LAT_H, LAT_W], "denoise_steps": [args.denoise_steps or 25, args.denoise_steps or 30],
-                       "parallelism": plan.describe(), "precision_plan": precision_plan(),
+                       "parallelism": plan.describe(), "precision_plan": precision_plan(), "kernel_switches": kernel_switches(),
                        "weights": "seeded random, reference architecture (1.59 B + 0.67 B + 64 M parameters)"},
             "roofline": roof, "cpu_baseline": cpu, "stages": stages}))
     if world > 1:
@@ -678,7 +685,7 @@ def run_full(args, rank, world, device):
                                                    "6 (window, CFG half) units + the key-frame pre-pass's 2 over the ranks of the video's group, one all-gather per DDIM step"
                                                    if pipe.group is not None else "single GPU"),
                                        "vfi": ("frame pairs sharded over the ranks of the video's group" if pipe.group is not None else "single GPU")},
-                       "precision_plan": precision_plan(),
+                       "precision_plan": precision_plan(), "kernel_switches": kernel_switches(),
                        "weights": "seeded random, reference architectures (StreamingSVD 2.3 B, I2VGen-XL 1.42 B, AutoencoderKL, CLIP ViT-H/14 image tower, EMA-VFI 65.7 M); "
                                   "CLIP text tower replaced by fixed random prompt embeddings"},
             "roofline": roof, "cpu_baseline": cpu}))

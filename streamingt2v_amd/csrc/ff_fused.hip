@@ -61,6 +61,9 @@ constexpr int FF_LDS_TOTAL = FF_LDS_B2 + FF_C * 4;             // 126 208 B
 // x + time_pos_embed, norm1 behind ff_in; video_attention.py:125-168,318-321): the 32 lanes of a half-wave hold the same 16 tokens, so the statistics are a 32-lane
 // butterfly per token over this wave's NO x 32 channels; in the eight-wave form (PAIRX) the two waves of a pair hold one half of a token's 320 channels each and merge
 // (mean, M2) of their halves through LDS (Chan's parallel update: exact, one exchange, one workgroup barrier).
+#ifndef SVD_FF_LN_PROBE
+#define SVD_FF_LN_PROBE 0          // developer builds only (cost attribution of the LayerNorm epilogue): 1 no Yn stores, 2 no wave-pair exchange / barrier, 4 no reductions
+#endif
 struct FfLn { const float* gamma; const float* beta; float eps; const float* addvec; svd_bf16* Yn; int64_t ldyn; float* xch_own; const float* xch_other; };
 template <class E, int RES, bool OUT32, bool BLEND, int NO, bool LN, bool PAIRX>
 __device__ __forceinline__ void ff_epilogue(f32x16_t (&acc)[NO], int rbase, int M, int ch0, int l31, int hi, const float* bl, const float* vecp, const void* __restrict__ R,
@@ -135,16 +138,16 @@ __device__ __forceinline__ void ff_epilogue(f32x16_t (&acc)[NO], int rbase, int 
             float sm = 0.f;
 #pragma unroll
             for (int o = 0; o < NO; ++o) sm += acc[o][r];
-            mean[r] = half_wave_sum(sm) * inv_w;
+            mean[r] = ((SVD_FF_LN_PROBE & 4) ? sm : half_wave_sum(sm)) * inv_w;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float sq = 0.f;
 #pragma unroll
             for (int o = 0; o < NO; ++o) { const float d = acc[o][r] - mean[r]; sq += d * d; }
-            m2[r] = half_wave_sum(sq);
+            m2[r] = (SVD_FF_LN_PROBE & 4) ? sq : half_wave_sum(sq);
         }
-        if constexpr (PAIRX) {
+        if constexpr (PAIRX && !(SVD_FF_LN_PROBE & 2)) {
             if (l31 == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) *(float4*)(ln.xch_own + hi * 32 + 2 * r) = make_float4(mean[r], m2[r], mean[r + 1], m2[r + 1]);
@@ -167,7 +170,11 @@ __device__ __forceinline__ void ff_epilogue(f32x16_t (&acc)[NO], int rbase, int 
             const int t = rbase + (r & 3) + 8 * (r >> 2);
             svd_bf16* np = ln.Yn + (int64_t)(t < M ? t : M - 1) * ln.ldyn + ch0;
 #pragma unroll
-            for (int o = 0; o < NO; ++o) np[32 * o] = E::from_f32((acc[o][r] - mean[r]) * rstd * gam[o] + bet[o]);
+            for (int o = 0; o < NO; ++o) {
+                const svd_bf16 q = E::from_f32((acc[o][r] - mean[r]) * rstd * gam[o] + bet[o]);
+                if constexpr (SVD_FF_LN_PROBE & 1) asm volatile("" :: "v"(q));
+                else np[32 * o] = q;
+            }
         }
     }
 }
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
                                                                 const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec,
                                                                 const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps,
                                                                 const float* __restrict__ ln_addvec, int ln_addvec_ld, int ln_rows_per_vec,
-                                                                svd_bf16* __restrict__ Yn, int64_t ldyn) {
+                                                                svd_bf16* __restrict__ Yn, int64_t ldyn, int stagger_ticks, int stagger_from) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ff_start_delay();
     const uint32_t sbase = lds_addr_of(smem);
@@ -271,6 +278,14 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_fused_kernel(const svd_bf16* 
     __syncthreads();
 
     f32x16_t s_a[2], s_b[2];
+    // PHASE STAGGER (round 6): the workgroups of a launch start together and every tile takes the same time, so all 256 CUs reach their epilogue -- the part of a tile
+    // that moves its HBM bytes (residual in, rows out) -- at the same moment, then leave the memory system idle through the next tile's MFMA phases.  The workgroups from
+    // `stagger_from` on start `stagger_ticks` (100 MHz wall clock; half a tile) late: two groups in anti-phase.  The host picks them among the workgroups that own one
+    // tile less than the others, so the delay hides in the tail of the launch.  Measured 1-2 % of the kernel (profiles/r06_ff_stagger_ab.txt).
+    if (stagger_ticks > 0 && (int)blockIdx.x >= stagger_from) {
+        const long long until = wall_clock64() + stagger_ticks;
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(64);
+    }
     for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
         for (int o = 0; o < FF_NO; ++o)
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16*
                                                                  const float* __restrict__ rowvec, int rowvec_ld, int rows_per_vec,
                                                                  const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps,
                                                                  const float* __restrict__ ln_addvec, int ln_addvec_ld, int ln_rows_per_vec,
-                                                                 svd_bf16* __restrict__ Yn, int64_t ldyn) {
+                                                                 svd_bf16* __restrict__ Yn, int64_t ldyn, int stagger_ticks, int stagger_from) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t sbase = lds_addr_of(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -505,6 +520,14 @@ __global__ __launch_bounds__(512, 1) void ff_geglu_fused8_kernel(const svd_bf16*
     svd_wait_dma();
     __syncthreads();
 
+    // PHASE STAGGER (round 6): the workgroups of a launch start together and every tile takes the same time, so all 256 CUs reach their epilogue -- the part of a tile
+    // that moves its HBM bytes (residual in, rows out) -- at the same moment, then leave the memory system idle through the next tile's MFMA phases.  The workgroups from
+    // `stagger_from` on start `stagger_ticks` (100 MHz wall clock; half a tile) late: two groups in anti-phase.  The host picks them among the workgroups that own one
+    // tile less than the others, so the delay hides in the tail of the launch.  Measured 1-2 % of the kernel (profiles/r06_ff_stagger_ab.txt).
+    if (stagger_ticks > 0 && (int)blockIdx.x >= stagger_from) {
+        const long long until = wall_clock64() + stagger_ticks;
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(64);
+    }
     f32x16_t s_a, s_b;
     for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
@@ -641,6 +664,16 @@ extern "C" { int svd_ff_probe_variant = 0; }      // 1..4 / 101..116: timing pro
 #else
 #define FF_FORCE4
 #endif
+// SVD_FF_STAGGER=<us> (default FF_STAGGER_US = half a tile's time; 0 = off): phase stagger of the workgroups, see the kernels
+#ifndef FF_STAGGER_US
+#define FF_STAGGER_US 45
+#endif
+static int ff_stagger_ticks() {
+    int us = FF_STAGGER_US;
+    if (const char* e = getenv("SVD_FF_STAGGER")) us = atoi(e);
+    return (us < 0 || us > 1000) ? 0 : us * 100;
+}
+
 extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t channels, int32_t hidden, const float* b2, const void* R,
                                   int64_t ldr, const void* S, int64_t lds, float alpha, int32_t res_f32, void* Y, int64_t ldy, int32_t out_f32, int64_t M,
                                   int32_t dtype, const float* rowvec, int32_t rowvec_ld, int32_t rows_per_vec, const float* ln_gamma, const float* ln_beta,
@@ -670,6 +703,12 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
     }
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     const int nch = hidden / 32;
+    // stagger only where a workgroup walks several tiles and some workgroups own one tile less than others (their delay is then free): the late group is the upper half
+    // of the grid, or what of it owns the smaller tile count
+    static const int stg_ticks = ff_stagger_ticks();
+    const int rem = ntiles % grid;
+    const int stagger_from = rem > grid / 2 ? rem : grid / 2;
+    const int stagger_ticks = (ntiles >= 4 * n_cu && rem != 0) ? stg_ticks : 0;
     // SVD_FF_WAVES=4 (A/B switch): the four-wave form (one wave per SIMD) instead of the eight-wave one (wave pairs, two per SIMD).  The two are
     // bit-identical.  Before the epilogue's residual loads were batched they were equally fast (1.39 vs 1.38 ms at M = 460 800, stage-1 line 2.2823 vs 2.2824
     // frames/s); with the batched epilogue the eight-wave form is ahead (1.24 vs 1.31 ms; same-box stage-1 line 2.336 vs 2.318, AR chunk 7.48 vs 7.53 s:
@@ -689,7 +728,7 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
                     attr_set = true;                                                                                                     \
                 }                                                                                                                        \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
-                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn);                                                                                      \
+                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn, stagger_ticks, stagger_from);                                                                                      \
             } else {                                                                                                                     \
                 auto kern = ff_geglu_fused8_kernel<E, RES, OUT, BL, 0, LNV>;                                                                      \
                 static unsigned char attr_set_dev[64] = {0};                                                                             \
@@ -699,7 +738,7 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
                     attr_set = true;                                                                                                     \
                 }                                                                                                                        \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, \
-                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn);                                                                                      \
+                                   alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn, stagger_ticks, stagger_from);                                                                                      \
             }                                                                                                                            \
         });                                                                                                                              \
     } while (0)
@@ -709,13 +748,13 @@ extern "C" int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp
         do {                                                                                                                             \
             auto kern = ff_geglu_fused_kernel<ElemF16, 2, true, false, PVV>;                                                                   \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FF_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn, stagger_ticks, stagger_from); \
         } while (0)
 #define FF_PROBE8(PVV)                                                                                                                   \
         do {                                                                                                                             \
             auto kern = ff_geglu_fused8_kernel<ElemF16, 2, true, false, PVV>;                                                              \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_TOTAL) != hipSuccess) return SVD_ELAUNCH; \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F8_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, nch, b2, R, ldr, S, lds, alpha, Y, ldy, (int)M, ntiles, rowvec, rowvec_ld, rows_per_vec, ln_gamma, ln_beta, ln_eps, ln_addvec, ln_addvec_ld, ln_rows_per_vec, Yn, ldyn, stagger_ticks, stagger_from); \
         } while (0)
         switch (svd_ff_probe_variant) {
             case 1: FF_PROBE(1); break; case 2: FF_PROBE(2); break; case 3: FF_PROBE(3); break; case 4: FF_PROBE(4); break;

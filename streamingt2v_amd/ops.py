@@ -365,7 +365,10 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, blend=N
 # FUSED FEED-FORWARD (round 5, csrc/ff_fused.hip): LayerNorm output -> GEGLU projection -> gate -> down-projection (+ residual, + blend) in ONE
 # launch for the 320-channel blocks; the [M, 1280] hidden activation never reaches HBM.  SVD_FF_FUSED=0 keeps the two svd_gemm launches (A/B).
 FF_FUSED = _os.environ.get("SVD_FF_FUSED", "1") != "0"
-FF_FUSED_LN = _os.environ.get("SVD_FF_FUSED_LN", "1") != "0"      # (A/B) the LayerNorm behind a feed-forward from the fused kernel's epilogue (round 6)
+# the LayerNorm behind a feed-forward from the fused kernel's own epilogue (round 6, ABI v10).  Built, parity-tested -- and OFF: 1.54 ms against 1.27 + 0.19 ms for the
+# two kernels at M = 460 800, -0.5 % on the stage-1 job (profiles/r06_ff_ln_kernel_ab.txt, r06_bench6_ff_ln_ab.txt): the kernel's eight waves reach the epilogue together,
+# the second store stream and the 22 spilled registers are exposed there.  SVD_FF_FUSED_LN=1 selects it.
+FF_FUSED_LN = _os.environ.get("SVD_FF_FUSED_LN", "0") == "1"
 
 
 def ff_fused_ok(channels, hidden):
