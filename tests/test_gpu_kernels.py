@@ -57,6 +57,47 @@ def test_gemm_plain(ops, cfg, M, N, K):
     check(f"gemm-select cfg{cfg}", out, w.float().t()[idx], 1e-6, 0)
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 8, 20, 21, 22])
+def test_gemm_w_panel_walk(ops, cfg, monkeypatch):
+    """The W-panel tile walk (csrc/gemm_impl.inc, round 6: when W exceeds an XCD's L2 the tiles are walked panel by panel of N tiles instead of N fastest over
+    the whole width) visits every output tile exactly once, whatever the panel width: bit-identical to the N-fastest walk (SVD_GEMM_PANEL=0) for the width the
+    traffic model picks and for forced widths that leave a narrower last panel, with the per-tile epilogue operands (bias slice, per-frame vector, residual) and
+    a ragged last M tile and N tile; and equal to plain fp32 PyTorch."""
+    M, N, K, rpv = 16500, 2568, 1280, 1500                 # W = 6.6 MB; 65..130 x 9..21 tiles depending on the configuration
+    a, w = rnd(M, K, seed=31), rnd(N, K, scale=K ** -0.5, seed=32)
+    bias = rnd(N, seed=33, dtype=torch.float32)
+    rowvec = rnd(M // rpv, N, seed=34, dtype=torch.float32)
+    R = rnd(M, N, seed=35)
+    ref = a.float() @ w.float().t() + bias + rowvec.repeat_interleave(rpv, 0) + R.float()
+    outs = {}
+    for width in ("0", None, "1", "3", "7"):
+        if width is None:
+            monkeypatch.delenv("SVD_GEMM_PANEL", raising=False)
+        else:
+            monkeypatch.setenv("SVD_GEMM_PANEL", width)
+        outs[width] = ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_vec=rpv, residual=R, tile_cfg=cfg)
+    monkeypatch.delenv("SVD_GEMM_PANEL", raising=False)
+    check(f"gemm panel walk cfg{cfg} vs fp32 torch", outs["0"], ref, 3e-2, 1e-2)
+    for width, o in outs.items():
+        assert torch.equal(o, outs["0"]), f"panel width {width}: differs from the N-fastest walk"
+    if cfg in (21, 22):
+        return                                             # 320-wide tiles do not take the GEGLU epilogue (test_gemm_geglu's list)
+    # GEGLU projection (value | gate column pairs inside a tile) through the walk the model picks
+    from streamingt2v_amd.video_model import pack_geglu
+    Hd = 2560
+    w1 = rnd(2 * Hd, K, scale=K ** -0.5, seed=36).float().cpu()
+    b1 = rnd(2 * Hd, seed=37, dtype=torch.float32, scale=0.3).cpu()
+    w1p, b1p = pack_geglu(w1, b1)
+    w1p, b1p = w1p.to(BF16).cuda(), b1p.cuda()
+    monkeypatch.setenv("SVD_GEMM_PANEL", "0")
+    g0 = ops.gemm(a, w1p, bias=b1p, geglu=True, tile_cfg=cfg)
+    monkeypatch.delenv("SVD_GEMM_PANEL", raising=False)
+    g1 = ops.gemm(a, w1p, bias=b1p, geglu=True, tile_cfg=cfg)
+    assert torch.equal(g0, g1)
+    h = a.float() @ w1.to(BF16).float().cuda().t() + b1.cuda()
+    check(f"gemm panel walk cfg{cfg} GEGLU vs fp32 torch", g1, h[:, :Hd] * F.gelu(h[:, Hd:]), 3e-2, 1e-2)
+
+
 def test_gemm_k32_and_f32_out(ops):
     M, N, K = 513, 132, 96
     a, w = rnd(M, K, seed=4), rnd(N, K, scale=K ** -0.5, seed=5)
