@@ -312,6 +312,17 @@ int svd_ff_geglu_fused(const svd_bf16* X, int64_t ldx, const void* Wp, int32_t c
                        const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_addvec, int32_t ln_addvec_ld, int32_t ln_rows_per_vec,
                        svd_bf16* Yn, int64_t ldyn, svd_stream_t stream);
 
+/* Row-resident 320 -> N projection (ABI v11, round 6, csrc/rowproj.hip):  Y[M, N] = X[M, 320] . W^T + bias, 16-bit rows in and out, N % 64 == 0.
+ * Replaces svd_gemm for the q | k (N = 640) and q | k | v (N = 960) projections of the 320-channel transformer blocks (attn1.to_q / to_k of
+ * SpatialVideoTransformer, to_q / to_k / to_v of its time_stack: sgm/modules/attention.py:246-262, video_attention.py:125-168; the enhancer's Transformer2DModel /
+ * TransformerTemporalModel): a wave keeps its 32 token rows in registers for the whole width, so X is read once instead of once per N tile.
+ *   Wp   packed weights (svd_rowproj320_pack_bytes(N) bytes, video_model.pack_rowproj320): chunk ch of 64 channels = 40 fragments of 1 KiB, fragment 2 s + t
+ *        (k-step s of 20, tile t of 2), lane l: W[64 ch + 2 (l % 32) + t][16 s + 8 (l / 32) .. + 7] in the element type
+ *   bias fp32 [N] or NULL;  ldx % 8 == 0, ldy % 2 == 0 (elements), Y 4-byte aligned */
+int64_t svd_rowproj320_pack_bytes(int32_t N);
+int svd_rowproj320(const svd_bf16* X, int64_t ldx, const void* Wp, const float* bias, svd_bf16* Y, int64_t ldy, int64_t M, int32_t N, int32_t dtype,
+                   svd_stream_t stream);
+
 /* Row-owning 320 -> 320 projection of the fp32 residual stream, optionally with the LayerNorm that follows it (ABI v9, round 6):
  *     V  = R + bias + rowvec[row / rows_per_vec] + X . W^T                  -> Y  (fp32 rows when out_f32, else 16-bit rows; may be NULL when Yn is given)
  *     Yn = LayerNorm(V; ln_gamma, ln_beta, ln_eps)                          -> 16-bit rows (NULL: no LayerNorm)

@@ -30,7 +30,7 @@ def _lib_file():
 
 LIB_PATH = os.path.join(_HERE, _lib_file())
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # entry points include/svdhip.h declares (checked at load; tests/test_abi.py re-checks against the header text)
 SYMBOLS = [
@@ -40,7 +40,7 @@ SYMBOLS = [
     "svd_nchw_to_tokens", "svd_nchw_to_tokens_x3", "svd_rows_split3", "svd_add_rows_bf32", "svd_head_gn_silu_conv3x3", "svd_tokens_to_nchw", "svd_concat_channels", "svd_add_rows", "svd_cast_f32", "svd_cast_rows_f32", "svd_permute_rows",
     "svd_timestep_embedding", "svd_edm_euler_step", "svd_ae_time_mix3",
     "svd_attn_cross_d64", "svd_adaptive_avgpool_tokens", "svd_i2v_image_temporal_encoder", "svd_ddim_cfg_step", "svd_frames_to_uint8", "svd_gelu_rows",
-    "svd_ff_geglu_fused", "svd_ff_fused_pack_bytes", "svd_rowgemm320", "svd_rowgemm320_pack_bytes",
+    "svd_ff_geglu_fused", "svd_ff_fused_pack_bytes", "svd_rowgemm320", "svd_rowgemm320_pack_bytes", "svd_rowproj320", "svd_rowproj320_pack_bytes",
     "svd_prelu_rows", "svd_dwconv3x3_gelu", "svd_window_attn_7x7", "svd_warp_bilinear", "svd_resize_bilinear_f32", "svd_vfi_merge", "svd_vfi_tta_average",
 ]
 
@@ -140,6 +140,9 @@ def _load():
     lib.svd_rowgemm320_pack_bytes.restype = C.c_int64
     lib.svd_rowgemm320_pack_bytes.argtypes = []
     lib.svd_rowgemm320.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, i64, vp, i64, i32, vp, vp, f32, vp, i64, i64, i32, vp]
+    lib.svd_rowproj320_pack_bytes.restype = C.c_int64
+    lib.svd_rowproj320_pack_bytes.argtypes = [i32]
+    lib.svd_rowproj320.argtypes = [vp, i64, vp, vp, vp, i64, i64, i32, i32, vp]
     lib.svd_prelu_rows.argtypes = [vp, i64, i64, i32, vp, i32, vp]
     lib.svd_dwconv3x3_gelu.argtypes = [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.svd_window_attn_7x7.argtypes = [vp, i64, vp, i64, vp, i64, vp, i32, vp, i64, vp, i64, i32, i32, i32, f32, i32, vp]
@@ -149,7 +152,7 @@ def _load():
     lib.svd_vfi_tta_average.argtypes = [vp, vp, vp, i32, i32, vp]
     for s in SYMBOLS:
         fn = getattr(lib, s)
-        if s not in ("svd_last_error", "svd_groupnorm_partial_elems", "svd_ff_fused_pack_bytes", "svd_rowgemm320_pack_bytes"):
+        if s not in ("svd_last_error", "svd_groupnorm_partial_elems", "svd_ff_fused_pack_bytes", "svd_rowgemm320_pack_bytes", "svd_rowproj320_pack_bytes"):
             fn.restype = C.c_int
     if lib.svd_abi_version() != ABI_VERSION:
         raise ImportError(f"libsvdhip.so ABI {lib.svd_abi_version()} != binding ABI {ABI_VERSION}; rebuild")

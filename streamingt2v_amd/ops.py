@@ -474,6 +474,37 @@ def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=Non
     return y, yn
 
 
+# ROW-RESIDENT 320 -> N PROJECTION (round 6, csrc/rowproj.hip): the q | k and q | k | v projections of the 320-channel transformer blocks read their rows ONCE for
+# the whole width (a wave keeps its 32 rows in registers; the 256 x 320 GEMM tile re-reads them per N tile).  SVD_ROWPROJ=0 keeps svd_gemm (A/B).
+ROWPROJ = _os.environ.get("SVD_ROWPROJ", "1") != "0"
+ROWPROJ_MIN_ROWS = int(_os.environ.get("SVD_ROWPROJ_MIN_ROWS", "65536"))
+
+
+def rowproj_ok(x, w_img):
+    return ROWPROJ and w_img is not None and x.shape[1] == 320 and x.shape[0] >= ROWPROJ_MIN_ROWS
+
+
+def rowproj320(x, w_img, n_out, *, bias=None, out=None):
+    """x [M, 320] 16-bit rows; w_img = video_model.pack_rowproj320(W [n_out, 320]) on the device (uint8).  Returns x W^T + bias, [M, n_out] in the 16-bit type."""
+    assert x.dtype in (BF16, F16) and x.is_cuda and x.stride(1) == 1 and x.shape[1] == 320 and w_img.dtype == torch.uint8 and n_out % 64 == 0
+    assert w_img.numel() == (n_out // 64) * 40960
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    assert out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == x.dtype and out.stride(0) % 2 == 0
+    flops = 2.0 * M * n_out * 320
+    nbytes = float(M * (320 + n_out) * 2 + w_img.numel())
+    if worklog is not None:
+        _wl("rowproj320_kernel", flops, nbytes)
+    args = (_p(x), x.stride(0), _p(w_img), _p(bias), _p(out), out.stride(0), M, n_out, _dt(x), _stream())
+    if trace is not None:
+        with trace.launch("rowproj320", flops=flops, sig=f"rowproj_M{M}_N{n_out}", nbytes=nbytes):
+            check(_lib.svd_rowproj320(*args), "svd_rowproj320")
+        return out
+    check(_lib.svd_rowproj320(*args), "svd_rowproj320")
+    return out
+
+
 def attn_spatial(q, k, vt, out, frames, n_tok, heads):
     """q,k: views into a [frames*n_tok, ld] tensor at the head-0 column; vt: [frames, heads*64, tok_ld]."""
     if worklog is not None:

@@ -106,6 +106,20 @@ def pack_rowgemm320(w):
     return img.view(-1).view(torch.uint8)
 
 
+def pack_rowproj320(w):
+    """Linear(320, N) weight [N, 320] (N % 64 == 0) -> the packed image of svd_rowproj320 (csrc/rowproj.hip), a uint8 tensor: per chunk of 64 output channels 40 MFMA
+    B-operand fragments of 1 KiB, fragment 2 s + t (k-step s of 20, column tile t of 2): lane l holds W[64 ch + 2 (l % 32) + t][16 s + 8 (l // 32) .. + 7] -- the
+    chunk's channels interleaved over its two column tiles, so that a lane's two accumulators are ADJACENT channels (one dword store)."""
+    N = w.shape[0]
+    assert w.shape[1] == 320 and N % 64 == 0
+    w = w.detach().float().cpu()
+    ar = torch.arange
+    ch, s_, t, l, e = (ar(N // 64).view(-1, 1, 1, 1, 1), ar(20).view(1, -1, 1, 1, 1), ar(2).view(1, 1, -1, 1, 1), ar(64).view(1, 1, 1, -1, 1),
+                       ar(8).view(1, 1, 1, 1, -1))
+    img = w[64 * ch + 2 * (l & 31) + t, 16 * s_ + 8 * (l >> 5) + e].to(ops.ELEM).contiguous()
+    return img.view(-1).view(torch.uint8)
+
+
 class RowProj:
     """A 320 -> 320 projection of the fp32 residual stream, optionally with the LayerNorm that consumes its result: ONE launch of svd_rowgemm320 where that
     kernel applies (dim 320, fp32 stream, the per-frame vector constant inside a 32-row tile), else svd_gemm (+ svd_layernorm).
@@ -380,6 +394,12 @@ class SpatialVideoTransformer:
         if self.c == 320:
             R = lambda k: pack_rowgemm320(g(k)).to(dev)
             self.rg = dict(pi=R("proj_in.weight"), so=R(b + "attn1.to_out.0.weight"), to=R(t + "attn1.to_out.0.weight"), po=R("proj_out.weight"), dtype=ops.ELEM)
+        # ... and the q | k / q | k | v projections in the row-resident kernel's (ops.rowproj320, csrc/rowproj.hip): the same concatenated weights as s_wqk / t_wqkv
+        self.rp = None
+        if self.c == 320:
+            cat = lambda *ks: torch.cat([g(k) for k in ks], 0)
+            self.rp = dict(sqk=pack_rowproj320(cat(b + "attn1.to_q.weight", b + "attn1.to_k.weight")).to(dev),
+                           tqkv=pack_rowproj320(cat(t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight")).to(dev), dtype=ops.ELEM)
         self.tp_w0, self.tp_b0 = W("time_pos_embed.0.weight"), Fv("time_pos_embed.0.bias")
         self.tp_w2, self.tp_b2 = W("time_pos_embed.2.weight"), Fv("time_pos_embed.2.bias")
         self.alpha = _sigmoid(g("time_mixer.mix_factor"))
@@ -474,7 +494,8 @@ class SpatialVideoTransformer:
         else:
             h = ops.gemm(h, self.wpi, bias=self.bpi, out_f32=st)
             n1 = ops.layernorm(h, *self.s_ln["norm1"])
-        qk = ops.gemm(n1, self.s_wqk)
+        rp = self.rp if (self.rp is not None and n1.dtype == self.rp["dtype"]) else None
+        qk = ops.rowproj320(n1, rp["sqk"], 2 * c) if (rp is not None and ops.rowproj_ok(n1, rp["sqk"])) else ops.gemm(n1, self.s_wqk)
         vt, tok_ld = self._vt_buf(F, pix, e16)
         ops.gemm(n1, self.s_wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
         a = torch.empty((M, c), dtype=e16, device=x.device)
@@ -501,7 +522,7 @@ class SpatialVideoTransformer:
         if nin is None:
             nin = ops.layernorm(ht, *self.t_ln["norm_in"], addvec=temb, rows_per_vec=pt)
         xm, n1 = self.t_ff_in(nin, residual=ht, out_f32=st, rowvec=temb, rows_per_vec=pt, ln=self.t_ln["norm1"])
-        qkv = ops.gemm(n1, self.t_wqkv)
+        qkv = ops.rowproj320(n1, rp["tqkv"], 3 * c) if (rp is not None and ops.rowproj_ok(n1, rp["tqkv"])) else ops.gemm(n1, self.t_wqkv)
         at = torch.empty((B * T * pt, c), dtype=e16, device=x.device)
         ops.attn_temporal(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], at, B, T, T, pt, heads)
         n3 = None

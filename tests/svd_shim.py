@@ -345,6 +345,36 @@ def _rowgemm_unpack(img, dtype):
     return w
 
 
+def _rowproj_unpack(img, dtype, n_out):
+    """inverse of video_model.pack_rowproj320: image [N / 64 chunks, 20 k-steps, 2 tiles, 64 lanes, 8] -> W [N, 320] fp32"""
+    f = img.view(dtype).view(n_out // 64, 20, 2, 64, 8).float()
+    ar = torch.arange
+    ch, s_, t, l, e = (ar(n_out // 64).view(-1, 1, 1, 1, 1), ar(20).view(1, -1, 1, 1, 1), ar(2).view(1, 1, -1, 1, 1), ar(64).view(1, 1, 1, -1, 1),
+                       ar(8).view(1, 1, 1, 1, -1))
+    w = torch.zeros(n_out, 320)
+    w[(64 * ch + 2 * (l & 31) + t + 0 * (s_ + e)).expand_as(f), (16 * s_ + 8 * (l >> 5) + e + 0 * (ch + t)).expand_as(f)] = f
+    return w
+
+
+def rowproj_ok(x, w_img):
+    return w_img is not None and x.shape[1] == 320
+
+
+def rowproj320(x, w_img, n_out, *, bias=None, out=None):
+    """csrc/rowproj.hip: y = x W^T + bias (include/svdhip.h svd_rowproj320)."""
+    from streamingt2v_amd import ops
+    if not hasattr(w_img, "_rp_unpacked"):
+        w_img._rp_unpacked = _rowproj_unpack(w_img.cpu(), ops.ELEM, n_out).to(x.device)
+    y = x.float() @ w_img._rp_unpacked.t()
+    if bias is not None:
+        y = y + bias
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def rowgemm320(x, w_img, *, bias=None, rowvec=None, rows_per_vec=0, residual=None, out_f32=True, ln=None, eps=1e-5, want_y=True, out=None):
     """csrc/rowgemm.hip: y = residual + bias + rowvec[row // rows_per_vec] + x W^T; yn = LayerNorm(y) (include/svdhip.h svd_rowgemm320)."""
     if not hasattr(w_img, "_rg_unpacked"):
@@ -403,7 +433,7 @@ def ddim_cfg_step(x, pred_uncond, pred_cond, guidance_scale, alpha_t, alpha_prev
 
 NAMES = ("gemm", "attn_spatial", "attn_temporal", "attn_cross", "groupnorm", "groupnorm_sums", "groupnorm_apply_sums", "layernorm", "nchw_to_tokens",
          "tokens_to_nchw", "concat_channels", "add_rows", "to_elem", "to_elem_rows", "permute_rows", "timestep_embedding", "edm_euler_step", "softmax_rows", "ae_time_mix3",
-         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder", "ff_geglu_fused", "ddim_cfg_step", "rowgemm320", "rowgemm_ok")
+         "nchw_to_tokens_x3", "rows_split3", "add_rows_f32b", "head_gn_silu_conv3x3", "adaptive_avgpool", "i2v_image_temporal_encoder", "ff_geglu_fused", "ddim_cfg_step", "rowgemm320", "rowgemm_ok", "rowproj320", "rowproj_ok")
 
 
 def install(monkeypatch=None):
@@ -418,8 +448,10 @@ def install(monkeypatch=None):
         else:
             setattr(ops, n, fn)
     if monkeypatch is not None:
+        monkeypatch.setattr(ops, "ROWPROJ_MIN_ROWS", 0, raising=False)
         monkeypatch.setattr(ops, "ROWGEMM_PLAIN_MIN_ROWS", 0, raising=False)          # host-logic tests: every rowgemm320 call site, whatever the row count
         monkeypatch.setattr(ops, "ELEM", torch.float32)
     else:
         ops.ROWGEMM_PLAIN_MIN_ROWS = 0
+        ops.ROWPROJ_MIN_ROWS = 0
         ops.ELEM = torch.float32

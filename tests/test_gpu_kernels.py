@@ -265,6 +265,34 @@ def test_rowgemm320(ops, M):
     assert torch.equal(y2, y3) and torch.equal(yn2, yn3)
 
 
+@pytest.mark.parametrize("M", [1, 127, 128, 300, 33000 + 17])
+@pytest.mark.parametrize("N", [64, 640, 960])
+def test_rowproj320(ops, M, N):
+    """svd_rowproj320 (csrc/rowproj.hip; the q | k and q | k | v projections of the 320-channel transformer blocks, attention.py:246-262, video_attention.py:125-168):
+    (1) against svd_gemm, the launch it replaces -- same operands, fp32 accumulation in a different order, one 16-bit output rounding: at most one flipped rounding;
+    (2) against plain fp32 PyTorch.  An ASYMMETRIC weight catches a transposed fragment or a wrong channel interleave; M covers a single row, ragged 128-row tiles
+    (rows past M store duplicates of row M - 1), many tiles per workgroup; a strided destination (a column range of a wider buffer); run-to-run bit identity."""
+    from streamingt2v_amd.video_model import pack_rowproj320
+    x = rnd(M, 320, seed=71)
+    w = rnd(N, 320, scale=320 ** -0.5, seed=72).float().cpu()
+    w[:, :5] *= 3.0; w[3:7] *= 0.25; w[N - 1] *= 2.0
+    bias = rnd(N, seed=73, dtype=torch.float32, scale=0.3)
+    img = pack_rowproj320(w).cuda()
+    assert img.numel() == ops._lib.svd_rowproj320_pack_bytes(N)
+    wd = w.to(BF16).cuda()
+    ref = x.float() @ wd.float().t()
+    for b in (None, bias):
+        y = ops.rowproj320(x, img, N, bias=b)
+        two = ops.gemm(x, wd, bias=b)
+        assert y.dtype == BF16 and y.shape == (M, N)
+        check(f"rowproj320 M={M} N={N} bias={b is not None} vs svd_gemm", y, two, 1.2e-2, 8e-3)
+        check(f"rowproj320 M={M} N={N} bias={b is not None} vs fp32 torch", y, ref + (b if b is not None else 0), 1.2e-2, 8e-3)
+    wide = torch.full((M, N + 70), 7.0, dtype=BF16, device="cuda")
+    y2 = ops.rowproj320(x, img, N, bias=bias, out=wide[:, 6:6 + N])
+    assert torch.equal(y2, y) and torch.equal(wide[:, :6], torch.full_like(wide[:, :6], 7.0)) and torch.equal(wide[:, 6 + N:], torch.full_like(wide[:, 6 + N:], 7.0))
+    assert torch.equal(ops.rowproj320(x, img, N, bias=bias), y)
+
+
 def test_geglu_gate_function_against_exact_erf(ops):
     """The GEGLU epilogue's gate function alone, on every 16-bit gate value in [-9.5, 9.5]: value = 1 (bias only), gate = x through a unit
     weight, so the output is rn16(gelu(x)) -- the exact-erf GELU of the reference's GEGLU (attention.py:99-101) as csrc/svd_common.h

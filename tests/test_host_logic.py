@@ -809,3 +809,25 @@ def test_rowgemm320_weight_image_layout_and_round_trip():
         assert torch.equal(svd_shim._rowgemm_unpack(img, torch.float32), w)
     finally:
         ops.ELEM = prev
+
+
+def test_rowproj320_weight_image_layout_and_round_trip():
+    """video_model.pack_rowproj320 (the image svd_rowproj320 reads, include/svdhip.h): chunk ch, fragment 2 s + t, lane l, element e =
+    W[64 ch + 2 (l % 32) + t][16 s + 8 (l // 32) + e] -- the chunk's channels interleaved over the two column tiles; tests/svd_shim._rowproj_unpack inverts it."""
+    import torch
+    from streamingt2v_amd import ops
+    from streamingt2v_amd.video_model import pack_rowproj320
+    from tests import svd_shim
+    prev = ops.ELEM
+    ops.ELEM = torch.float32
+    try:
+        N = 960
+        w = torch.arange(N * 320, dtype=torch.float32).reshape(N, 320)               # every element distinct: W[n][k] = 320 n + k
+        img = pack_rowproj320(w)
+        assert img.dtype == torch.uint8 and img.numel() == (N // 64) * 40 * 64 * 8 * 4
+        f = img.view(torch.float32).view(N // 64, 20, 2, 64, 8)
+        for ch, s_, t, l, e in ((0, 0, 0, 0, 0), (14, 19, 1, 63, 7), (3, 7, 1, 37, 5), (9, 4, 0, 32, 3), (1, 0, 1, 31, 0)):
+            assert f[ch, s_, t, l, e].item() == 320 * (64 * ch + 2 * (l % 32) + t) + 16 * s_ + 8 * (l // 32) + e
+        assert torch.equal(svd_shim._rowproj_unpack(img, torch.float32, N), w)
+    finally:
+        ops.ELEM = prev

@@ -14,7 +14,10 @@ ops.set_element_dtype(dt)
 g = torch.Generator(device="cuda")
 g.manual_seed(0)
 # (name, M, N, K, geglu, fp32 residual / output)
-CASES = [("stage 1 level-1 GEGLU proj", 115200, 5120, 640, True, False), ("stage 1 level-2 GEGLU proj", 28800, 10240, 1280, True, False),
+CASES = [("stage 1 level-0 temporal q|k|v", 460800, 960, 320, False, False), ("stage 1 level-0 q|k", 460800, 640, 320, False, False),
+         ("stage 1 level-1 temporal q|k|v", 115200, 1920, 640, False, False), ("stage 1 level-1 q|k", 115200, 1280, 640, False, False),
+         ("enhancer level-0 q|k", 1094400, 640, 320, False, False),
+         ("stage 1 level-1 GEGLU proj", 115200, 5120, 640, True, False), ("stage 1 level-2 GEGLU proj", 28800, 10240, 1280, True, False),
          ("stage 1 level-3 GEGLU proj", 7200, 10240, 1280, True, False), ("stage 1 level-1 ff down", 115200, 640, 2560, False, True),
          ("stage 1 level-2 ff down", 28800, 1280, 5120, False, True), ("stage 1 level-2 q|k", 28800, 2560, 1280, False, False),
          ("stage 1 level-2 temporal q|k|v", 28800, 3840, 1280, False, False), ("enhancer level-1 GEGLU proj", 273600, 5120, 640, True, False),
@@ -35,7 +38,7 @@ def timed(fn, reps=10):
 
 
 print(f"{'case':34s} {'M':>7s} {'N':>6s} {'K':>5s}   N-fastest      default walk   forced widths (us)")
-for name, M, N, K, geglu, st in CASES:
+for name, M, N, K, geglu, st in (CASES[:5] if "--small-w" in sys.argv else CASES):
     a = torch.randn(M, K, generator=g, device="cuda").to(dt)
     w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(dt)
     bias = torch.randn(N, generator=g, device="cuda")
