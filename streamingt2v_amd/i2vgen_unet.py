@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from .params import Spec, check_state_dict
-from .video_model import FeedForward, RowProj, _dev_bf16, _dev_f32, _gn_pooled, _spec_ln, pack_conv3x3, pack_tconv3, pack_x3, pad_rows
+from .video_model import FeedForward, RowProj, WideProj, _dev_bf16, _dev_f32, _gn_pooled, _spec_ln, pack_conv3x3, pack_tconv3, pack_x3, pad_rows
 
 
 def _pad32(c):
@@ -173,7 +173,7 @@ class _Transformer2D:
         self.bpi, self.bpo = Fv("proj_in.bias"), Fv("proj_out.bias")
         b = "transformer_blocks.0."
         self.ln = {n: (Fv(b + n + ".weight"), Fv(b + n + ".bias")) for n in ("norm1", "norm2", "norm3")}
-        self.wqk = _dev_bf16(torch.cat([g(b + "attn1.to_q.weight"), g(b + "attn1.to_k.weight")], 0), dev)
+        self.wqk = WideProj(torch.cat([g(b + "attn1.to_q.weight"), g(b + "attn1.to_k.weight")], 0), dev)       # round 6: the row-resident kernel at C = 320
         self.wv, self.bo = W(b + "attn1.to_v.weight"), Fv(b + "attn1.to_out.0.bias")
         self.wq2, self.wk2, self.wv2 = W(b + "attn2.to_q.weight"), W(b + "attn2.to_k.weight"), W(b + "attn2.to_v.weight")
         self.bo2 = Fv(b + "attn2.to_out.0.bias")
@@ -205,7 +205,7 @@ class _Transformer2D:
         st = ops.i2v_stream_on(c)               # fp32 residual stream: h and the block output are fp32 between the kernels; every GEMM / attention operand is 16 bit
         e16 = ops.ELEM if x.dtype == torch.float32 else x.dtype
         h, n1 = self.p_in(ops.groupnorm(x, F, pix, *self.n, 1e-6), bias=self.bpi, ln=self.ln["norm1"], stream=st)
-        qk = ops.gemm(n1, self.wqk)
+        qk = self.wqk(n1)
         vt, tok_ld = self._vt_buf(F, pix, e16)
         ops.gemm(n1, self.wv, trans_out=dict(tok_per_frame=pix, tokens_ld=tok_ld, out=vt))
         a = torch.empty((M, c), dtype=e16, device=x.device)
@@ -239,7 +239,7 @@ class _TransformerTemporal:
         self.bpi, self.bpo = Fv("proj_in.bias"), Fv("proj_out.bias")
         b = "transformer_blocks.0."
         self.ln = {n: (Fv(b + n + ".weight"), Fv(b + n + ".bias")) for n in ("norm1", "norm2", "norm3")}
-        cat3 = lambda a: _dev_bf16(torch.cat([g(b + a + ".to_q.weight"), g(b + a + ".to_k.weight"), g(b + a + ".to_v.weight")], 0), dev)
+        cat3 = lambda a: WideProj(torch.cat([g(b + a + ".to_q.weight"), g(b + a + ".to_k.weight"), g(b + a + ".to_v.weight")], 0), dev)
         self.wqkv1, self.wqkv2 = cat3("attn1"), cat3("attn2")
         self.bo1, self.bo2 = Fv(b + "attn1.to_out.0.bias"), Fv(b + "attn2.to_out.0.bias")
         self.ff = FeedForward(g, b + "ff.", dev)
@@ -264,7 +264,7 @@ class _TransformerTemporal:
         h, n = self.p_in(hn, bias=self.bpi, ln=self.ln["norm1"], stream=st)
         a = torch.empty((M, d), dtype=e16, device=x.device)
         for nxt, wqkv, po, bo in (("norm2", self.wqkv1, self.p_o1, self.bo1), ("norm3", self.wqkv2, self.p_o2, self.bo2)):
-            qkv = ops.gemm(n, wqkv)
+            qkv = wqkv(n)
             ops.attn_temporal(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, B, Fr, Fr, pix_l, self.heads)
             h, n = po(a, bias=bo, residual=h, ln=self.ln[nxt], stream=st)      # ... and the LayerNorm the NEXT sub-block reads
         h = self.ff(n, residual=h)                                            # consumed by proj_out only: 16 bit

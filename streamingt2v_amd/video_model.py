@@ -139,6 +139,21 @@ class RowProj:
         return y, (ops.layernorm(y, *ln) if ln is not None else None)
 
 
+class WideProj:
+    """Fused q | k (| v) projection Linear(C, n C) without bias: svd_rowproj320 where that kernel applies (C = 320, enough rows), else svd_gemm.  __call__(x16) -> [M, n C]."""
+
+    def __init__(self, w, dev):
+        self.w = _dev_bf16(w, dev)
+        self.n_out = w.shape[0]
+        self.img = pack_rowproj320(w).to(dev) if (w.shape[1] == 320 and w.shape[0] % 64 == 0) else None
+        self.dtype = ops.ELEM
+
+    def __call__(self, x):
+        if self.img is not None and x.dtype == self.dtype and ops.rowproj_ok(x, self.img):
+            return ops.rowproj320(x, self.img, self.n_out)
+        return ops.gemm(x, self.w)
+
+
 class FeedForward:
     """FeedForward(dim, mult 4, glu=True) = GEGLU.proj -> value * gelu(gate) -> net[2] (attention.py:94-120; diffusers FeedForward "geglu" in the
     enhancer) on the kernel path: ONE launch of svd_ff_geglu_fused where the fused kernel exists (dim 320: the level-0 blocks, whose [M, 1280]
