@@ -17,6 +17,7 @@
 //     (First form: 4 waves, two slots, two workgroups per CU: 3.0 TB/s -- a chunk's copy, requested one step ahead, had not landed when the step began.)
 // Work per 256-row tile: N / 64 chunks x 40 MFMAs per wave against 160 KiB in + 256 N / 320 KiB out: HBM-bound at either width.
 #include "svd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -24,15 +25,21 @@ constexpr int RP_K = 320;
 constexpr int RP_NS = RP_K / 16;                    // 20 k-steps
 constexpr int RP_CH = 64;                           // output channels per chunk (two MFMA column tiles)
 constexpr int RP_CHUNK_BYTES = RP_NS * 2 * 1024;    // 40 fragments of 1 KiB: fragment 2 s + t
+constexpr int RP_DEFAULT_RB = 1;          // 2 once measured (SVD_ROWPROJ_RB selects)
 constexpr int RP_SLOTS = 3;                         // LDS ring: the copy of chunk g + 2 runs under the MFMAs of chunks g and g + 1
-constexpr int RP_LDS_TOTAL = RP_SLOTS * RP_CHUNK_BYTES;    // 120 KiB: one workgroup of eight waves per CU
-constexpr int RP_WAVES = 8;
-constexpr int RP_ROWS = RP_WAVES * 32;              // 256 token rows per tile
+constexpr int RP_LDS_TOTAL = RP_SLOTS * RP_CHUNK_BYTES;    // 120 KiB: one workgroup per CU
+constexpr int RP_ROWS = 256;                        // token rows per tile, either form
 
 // Fragment (k-step s, tile t) of chunk ch, lane l: W[64 ch + 2 (l % 32) + t][16 s + 8 (l / 32) .. + 7]  (video_model.pack_rowproj320)
-template <class E>
-__global__ __launch_bounds__(64 * RP_WAVES, 1) void rowproj320_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp,
+//
+// RB = 32-row blocks per wave.  RB = 1: eight waves (two per SIMD), each fragment read from LDS feeds ONE MFMA -- 8 waves x 40 KiB per chunk are 2 500 LDS cycles
+// against 2 560 matrix-pipe cycles per SIMD: the LDS port is as busy as the matrix pipe could be, and the kernel runs at 3 TB/s of its 4.5.  RB = 2: four waves
+// (one per SIMD) own 64 rows each, every fragment feeds TWO MFMAs (half the LDS reads per flop); 160 VGPRs of rows + 64 accumulators need the whole register file.
+template <class E, int RB>
+__global__ __launch_bounds__(64 * (8 / RB), 1) void rowproj320_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp,
                                                                       const float* __restrict__ bias, svd_bf16* __restrict__ Y, int64_t ldy, int M, int ntiles, int nch) {
+    constexpr int WAVES = 8 / RB, PIECES = 40 / WAVES, STORES = 16 * RB;
+    constexpr int INFLIGHT = PIECES + 2 * STORES < 63 ? PIECES + 2 * STORES : 63;       // vmcnt is a 6-bit counter
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t sbase = lds_addr_of(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -40,14 +47,14 @@ __global__ __launch_bounds__(64 * RP_WAVES, 1) void rowproj320_kernel(const svd_
     const int l31 = lane & 31, hi = lane >> 5;
     const uint32_t voff = (uint32_t)lane * 16u;
 
-    // LDS-DMA of one chunk: piece p (1 KiB) by wave p % 8, five pieces per wave (asm volatile without a memory clobber, like ff_fused.hip: the target slot is
-    // fenced off from its readers by the workgroup barriers either side)
+    // LDS-DMA of one chunk: piece p (1 KiB) by wave p % WAVES (asm volatile without a memory clobber, like ff_fused.hip: the target slot is fenced off from its
+    // readers by the workgroup barriers either side)
     auto dma_chunk = [&](int ch, int slot) __attribute__((always_inline)) {
         const char* src = Wp + (int64_t)ch * RP_CHUNK_BYTES;
         const uint32_t dst = sbase + slot * RP_CHUNK_BYTES;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int p = wave + RP_WAVES * i;
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = wave + WAVES * i;
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src + p * 1024), "s"(dst + p * 1024) : "m0");
         }
     };
@@ -59,27 +66,29 @@ __global__ __launch_bounds__(64 * RP_WAVES, 1) void rowproj320_kernel(const svd_
     dma_chunk(0, 0);
     if (total > 1) dma_chunk(1 % nch, 1);
     for (; tile < ntiles; tile += gridDim.x) {
-        // ---- the wave's 32 rows: lane (row l31, half hi) holds channels 16 s + 8 hi .. + 7 of k-step s; rows past M re-read row M - 1 (their stores are duplicates)
-        uint4 xf[RP_NS];
-        {
-            int row = tile * RP_ROWS + wave * 32 + l31;
+        // ---- the wave's rows: lane (row l31, half hi) of block rb holds channels 16 s + 8 hi .. + 7 of k-step s; rows past M re-read row M - 1 (their stores are duplicates)
+        uint4 xf[RB][RP_NS];
+        int64_t orow[RB][16];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int r0 = tile * RP_ROWS + (wave * RB + rb) * 32;
+            int row = r0 + l31;
             row = row < M ? row : M - 1;
             const svd_bf16* xp = X + (int64_t)row * ldx + 8 * hi;
 #pragma unroll
-            for (int s = 0; s < RP_NS; ++s) xf[s] = *(const uint4*)(xp + 16 * s);
-        }
-        int64_t orow[16];
+            for (int s = 0; s < RP_NS; ++s) xf[rb][s] = *(const uint4*)(xp + 16 * s);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = tile * RP_ROWS + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            orow[r] = (int64_t)(t < M ? t : M - 1) * ldy;
+            for (int r = 0; r < 16; ++r) {
+                const int t = r0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                orow[rb][r] = (int64_t)(t < M ? t : M - 1) * ldy;
+            }
         }
         for (int c = 0; c < nch; ++c, ++g) {
-            // vmcnt counts in order.  A step issues [5 pieces of chunk g + 2] [16 stores of chunk g]; chunk g's pieces were issued two steps ago, so "all but the 37
-            // youngest operations are done" = they have landed while the stores of the last two chunks stay in flight.  The first chunk of a tile also needs the
-            // tile's rows (the youngest operations), and the last two steps of the workgroup issue no pieces: everything.
+            // vmcnt counts in order.  A step issues [PIECES pieces of chunk g + 2] [STORES stores of chunk g]; chunk g's pieces were issued two steps ago, so "all but
+            // the PIECES + 2 STORES youngest operations are done" = they have landed while the stores of the last two chunks stay in flight.  The first chunk of a
+            // tile also needs the tile's rows (the youngest operations), and the last two steps of the workgroup issue no pieces: everything.
             if (c == 0 || g + 2 >= total) svd_wait_dma();
-            else asm volatile("s_waitcnt vmcnt(37)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
             __syncthreads();                         // everyone's pieces of chunk g have landed; and every wave has finished reading the slot of chunk g - 1
             if (g + 2 < total) {
                 int c2 = c + 2; c2 = c2 >= nch ? c2 - nch : c2; c2 = c2 >= nch ? c2 - nch : c2;       // the next tile starts with chunk 0 again (nch may be 1)
@@ -88,11 +97,13 @@ __global__ __launch_bounds__(64 * RP_WAVES, 1) void rowproj320_kernel(const svd_
             }
             float2 b = make_float2(0.f, 0.f);
             if (bias) b = *(const float2*)(bias + c * RP_CH + 2 * l31);
-            f32x16_t a0, a1;
+            f32x16_t a[RB][2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { a[rb][0][i] = 0.f; a[rb][1][i] = 0.f; }
             const char* wl = smem + slot * RP_CHUNK_BYTES + lane * 16;
-            // fragments three k-steps ahead through a ring of eight registers: an LDS read under load takes longer than the two MFMAs of a k-step
+            // fragments three k-steps ahead through a ring of eight registers: an LDS read under load takes longer than the MFMAs of a k-step
             constexpr int AH = 3;
             uint4 fr[8];
 #pragma unroll
@@ -104,13 +115,18 @@ __global__ __launch_bounds__(64 * RP_WAVES, 1) void rowproj320_kernel(const svd_
                     fr[(2 * (s + AH)) & 7] = *(const uint4*)(wl + (2 * (s + AH)) * 1024);
                     fr[(2 * (s + AH) + 1) & 7] = *(const uint4*)(wl + (2 * (s + AH) + 1) * 1024);
                 }
-                a0 = E::mfma(xf[s], fr[(2 * s) & 7], a0);
-                a1 = E::mfma(xf[s], fr[(2 * s + 1) & 7], a1);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    a[rb][0] = E::mfma(xf[rb][s], fr[(2 * s) & 7], a[rb][0]);
+                    a[rb][1] = E::mfma(xf[rb][s], fr[(2 * s + 1) & 7], a[rb][1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);          // pins the read-ahead distance (the scheduler otherwise sinks every read to its use)
             }
             uint32_t* yp = (uint32_t*)(Y + c * RP_CH) + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) *(uint32_t*)((svd_bf16*)yp + orow[r]) = E::pack(a0[r] + b.x, a1[r] + b.y);
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(uint32_t*)((svd_bf16*)yp + orow[rb][r]) = E::pack(a[rb][0][r] + b.x, a[rb][1][r] + b.y);
             slot = slot + 1 == RP_SLOTS ? 0 : slot + 1;
         }
     }
@@ -128,9 +144,9 @@ extern "C" int svd_rowproj320(const svd_bf16* X, int64_t ldx, const void* Wp, co
     const int ntiles = (int)((M + RP_ROWS - 1) / RP_ROWS);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SVD_ELAUNCH;
-#define RP_LAUNCH()                                                                                                                       \
+#define RP_LAUNCH(RBV)                                                                                                                    \
     SVD_DISPATCH_DTYPE(dtype, {                                                                                                           \
-        auto kern = rowproj320_kernel<E>;                                                                                                 \
+        auto kern = rowproj320_kernel<E, RBV>;                                                                                            \
         static int slots_e[64] = {0};        /* resident workgroups of this instantiation, per device (the attribute belongs to the device's copy) */ \
         int slots = __atomic_load_n(&slots_e[dev], __ATOMIC_RELAXED);                                                                     \
         if (!slots) {                                                                                                                     \
@@ -141,9 +157,11 @@ extern "C" int svd_rowproj320(const svd_bf16* X, int64_t ldx, const void* Wp, co
             __atomic_store_n(&slots_e[dev], slots, __ATOMIC_RELAXED);                                                                     \
         }                                                                                                                                 \
         const int grid = ntiles < slots ? ntiles : slots;                                                                                 \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RP_WAVES), RP_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, bias, Y, ldy, (int)M, ntiles, N / RP_CH); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (8 / RBV)), RP_LDS_TOTAL, (hipStream_t)stream, X, ldx, (const char*)Wp, bias, Y, ldy, (int)M, ntiles, N / RP_CH); \
     })
-    RP_LAUNCH();
+    // SVD_ROWPROJ_RB=1|2 (A/B): 32-row blocks per wave, see the kernel
+    static const int rb = [] { const char* e = getenv("SVD_ROWPROJ_RB"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : RP_DEFAULT_RB; }();
+    if (rb == 1) { RP_LAUNCH(1); } else { RP_LAUNCH(2); }
 #undef RP_LAUNCH
     SVD_CHECK_LAUNCH("rowproj320");
     return SVD_OK;
