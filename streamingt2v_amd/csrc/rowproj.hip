@@ -25,16 +25,18 @@ constexpr int RP_K = 320;
 constexpr int RP_NS = RP_K / 16;                    // 20 k-steps
 constexpr int RP_CH = 64;                           // output channels per chunk (two MFMA column tiles)
 constexpr int RP_CHUNK_BYTES = RP_NS * 2 * 1024;    // 40 fragments of 1 KiB: fragment 2 s + t
-constexpr int RP_DEFAULT_RB = 1;          // 2 once measured (SVD_ROWPROJ_RB selects)
+constexpr int RP_DEFAULT_RB = 1;          // measured faster than 2 (see the kernel); SVD_ROWPROJ_RB selects
 constexpr int RP_SLOTS = 3;                         // LDS ring: the copy of chunk g + 2 runs under the MFMAs of chunks g and g + 1
 constexpr int RP_LDS_TOTAL = RP_SLOTS * RP_CHUNK_BYTES;    // 120 KiB: one workgroup per CU
 constexpr int RP_ROWS = 256;                        // token rows per tile, either form
 
 // Fragment (k-step s, tile t) of chunk ch, lane l: W[64 ch + 2 (l % 32) + t][16 s + 8 (l / 32) .. + 7]  (video_model.pack_rowproj320)
 //
-// RB = 32-row blocks per wave.  RB = 1: eight waves (two per SIMD), each fragment read from LDS feeds ONE MFMA -- 8 waves x 40 KiB per chunk are 2 500 LDS cycles
-// against 2 560 matrix-pipe cycles per SIMD: the LDS port is as busy as the matrix pipe could be, and the kernel runs at 3 TB/s of its 4.5.  RB = 2: four waves
-// (one per SIMD) own 64 rows each, every fragment feeds TWO MFMAs (half the LDS reads per flop); 160 VGPRs of rows + 64 accumulators need the whole register file.
+// RB = 32-row blocks per wave.  RB = 1 (default): eight waves (two per SIMD), each fragment read from LDS feeds one MFMA.  RB = 2 (SVD_ROWPROJ_RB=2): four waves (one
+// per SIMD) own 64 rows each, every fragment feeds TWO MFMAs -- half the LDS reads per flop, accumulators in AGPRs, the k-loop is back-to-back MFMAs.  Measured
+// (profiles/r06_rowproj_probe.txt): RB = 2 is 5-8 % SLOWER (316 | 426 us against 298 | 395 us at M = 460 800, N = 640 | 960): the LDS port was not the limit, and one
+// wave per SIMD has nothing to run while it waits at the chunk barrier or packs its 64 accumulators.  Both forms sit at ~0.7 PFLOP/s -- about half of what the chip's
+// best GEMM sustains at its power-limited clock (MI355X_MICROARCH.md: 1.25-1.35 PFLOP/s) -- not at the 4.5 TB/s the bytes would allow.
 template <class E, int RB>
 __global__ __launch_bounds__(64 * (8 / RB), 1) void rowproj320_kernel(const svd_bf16* __restrict__ X, int64_t ldx, const char* __restrict__ Wp,
                                                                       const float* __restrict__ bias, svd_bf16* __restrict__ Y, int64_t ldy, int M, int ntiles, int nch) {
