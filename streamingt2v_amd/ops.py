@@ -227,7 +227,9 @@ def _load_tile_table():
     are not in the table use the heuristic of svd_gemm_pick_config."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tiles.json")
+    # SVD_GEMM_TILES=<file name next to this module> selects another table (A/B of a re-tuned table against the committed one)
+    name = os.path.basename(os.environ.get("SVD_GEMM_TILES", "gemm_tiles.json"))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     if not os.path.exists(path):
         return {}
     with open(path) as f:

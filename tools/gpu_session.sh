@@ -65,6 +65,15 @@ for step in "$@"; do
               timeout 300 python tools/rowproj_probe.py 2>&1 | grep -v amdgpu.ids > $O/rowproj_probe.txt; cat $O/rowproj_probe.txt ;;
     bench6rp) for v in 1 0 1 0; do SVD_ROWPROJ=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --no-stages > $O/bench6_rp$v.json 2>$O/bench6_rp$v.err; echo "SVD_ROWPROJ=$v"; cut -c1-120 $O/bench6_rp$v.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_rp$v.json; tail -1 $O/bench6_rp$v.err | cut -c1-200; done ;;
     enhrp)    for v in 1 0 1 0; do SVD_ROWPROJ=$v timeout 300 python bench.py --workload enhance --steps 1 --warmup 1 --no-cpu-baseline --no-trace > $O/enh_rp$v.json 2>/dev/null; echo "enhance, SVD_ROWPROJ=$v"; cut -c1-140 $O/enh_rp$v.json; done ;;
+    retune)   cp streamingt2v_amd/gemm_tiles.json streamingt2v_amd/gemm_tiles_prev.json; timeout 500 python tools/tune_gemm.py > $O/tune.log 2>$O/tune.err; cp streamingt2v_amd/gemm_tiles.json $O/gemm_tiles_retuned.json; head -5 $O/tune.log
+              python - <<'PY'
+import json
+a = json.load(open("streamingt2v_amd/gemm_tiles_prev.json"))["table"]; b = json.load(open("streamingt2v_amd/gemm_tiles.json"))["table"]
+ch = [(k, a[k]["cfg"], b[k]["cfg"]) for k in b if k in a and a[k]["cfg"] != b[k]["cfg"]]
+print(len(b), "signatures,", len(ch), "changed,", len([k for k in b if k not in a]), "new")
+for k, x, y in ch[:40]: print("  ", k, x, "->", y)
+PY
+              for v in gemm_tiles.json gemm_tiles_prev.json gemm_tiles.json gemm_tiles_prev.json; do SVD_GEMM_TILES=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --no-stages > $O/bench6_$v.out 2>/dev/null; echo "SVD_GEMM_TILES=$v"; cut -c1-120 $O/bench6_$v.out; done ;;
     svttests) timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stream_f32.py -m gpu -q -x -p no:cacheprovider > $O/svttests.log 2>&1; tail -4 $O/svttests.log ;;
     tailbench) for L in libsvdhip_pv_tail0.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_$L.json 2>/dev/null; echo $L; cut -c50-75 $O/bench6_$L.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_$L.json; done ;;
     geluab2)  for L in libsvdhip_pv_scalargelu.so libsvdhip.so libsvdhip_pv_scalargelu.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>&1 | tee -a $O/geglu_ab.txt; done ;;
