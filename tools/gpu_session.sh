@@ -16,6 +16,8 @@
 #   cfgab       tools/gemm_cfg_ab.py on a probe library with experimental tiles (CFGAB_LIB, CFGAB_CFGS): per-tile timings + bit checksums on the job's GEMM shapes
 #   tailab / tailbench   kernel tests + tools/geglu_ab.py (/ bench6) of libsvdhip.so against a variant library libsvdhip_pv_tail0.so (any GEMM-source A/B: build the variant's GEMM objects with the switch, link with the main objects)
 #   geluab(2)   A/B of the GEGLU epilogue against a variant library built with -DSVD_GEGLU_SCALAR_GELU (libsvdhip_pv_scalargelu.so): tests + tools/geglu_ab.py + bench6 (2: geglu_ab only)
+#   round 6: rowproj (kernel tests + tools/rowproj_probe.py), bench6rp / enhrp (SVD_ROWPROJ=1|0 on the stage-1 job / the enhancer window), paneltest / bench6panel (W-panel tile walk:
+#   GEMM tests, SVD_GEMM_PANEL=0 A/B), bench6stg (SVD_FF_STAGGER), bench6ln / fftest4 (the feed-forward's LayerNorm epilogue, both wave forms), retune (tile table re-tune + A/B), pmc6
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
 for step in "$@"; do
   echo "== $step"; t0=$(date +%s)
