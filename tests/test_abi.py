@@ -49,6 +49,25 @@ def test_argument_validation_without_gpu():
     bm, bn, th, lds = (ctypes.c_int() for _ in range(4))
     assert lib.svd_gemm_config_info(1, bm, bn, th, lds) == 0 and (bm.value, bn.value) == (128, 128)
     assert lib.svd_gemm_config_info(99, bm, bn, th, lds) == -1
+    # round-6 entry points: widths, alignments and option combinations are checked before the device is touched
+    buf = (ctypes.c_char * 4096)()
+    a16 = ctypes.cast(ctypes.addressof(buf) + (-ctypes.addressof(buf)) % 64, ctypes.c_void_p)          # a 64-byte aligned host address (never dereferenced)
+    assert lib.svd_rowproj320_pack_bytes(960) == 15 * 40960 and lib.svd_rowproj320_pack_bytes(100) == -1
+    assert lib.svd_rowproj320(a16, 320, a16, None, a16, 960, 128, 100, 1, None) == -1                # N % 64 != 0
+    assert lib.svd_rowproj320(a16, 320, a16, None, a16, 961, 128, 960, 1, None) == -1                # odd output row stride (dword stores)
+    assert lib.svd_rowproj320(a16, 316, a16, None, a16, 960, 128, 960, 1, None) == -1                # ldx < 320 / not a multiple of 8
+    assert lib.svd_rowproj320(None, 320, a16, None, a16, 960, 128, 960, 1, None) == -1
+    assert lib.svd_rowgemm320_pack_bytes() == 200 * 1024
+    assert lib.svd_rowgemm320(a16, 320, a16, None, None, 0, 0, None, 0, None, 0, 1, None, None, 1e-5, None, 0, 128, 1, None) == -1       # neither Y nor Yn
+    assert lib.svd_rowgemm320(a16, 320, a16, None, a16, 320, 48, None, 0, a16, 320, 1, None, None, 1e-5, None, 0, 128, 1, None) == -1    # rows_per_vec % 32 != 0
+    assert lib.svd_rowgemm320(a16, 320, a16, None, None, 0, 0, None, 0, a16, 320, 1, None, None, 1e-5, a16, 320, 128, 1, None) == -1     # Yn without gamma / beta
+    ff = lambda **kw: lib.svd_ff_geglu_fused(a16, 320, a16, kw.get("c", 320), kw.get("h", 1280), a16, kw.get("R"), 320, None, 0, 0.0, kw.get("r32", 0), a16, 320,
+                                             kw.get("o32", 0), 128, 1, kw.get("rv"), 320, kw.get("rpv", 0), kw.get("g"), kw.get("b"), 1e-5, None, 0, 0, kw.get("yn"), 320, None)
+    assert ff(c=640) == -1                                                                           # the fused kernel exists for dim 320
+    assert ff(rv=a16, rpv=48) == -1                                                                  # per-frame vector: rows_per_vec % 32
+    assert ff(yn=a16, g=a16, b=a16, R=a16, r32=0, o32=1) == -1                                       # fused LayerNorm needs the fp32 residual ...
+    assert ff(yn=a16, g=a16, b=a16, R=a16, r32=1, o32=0) == -1                                       # ... and the fp32 output
+    assert ff(yn=a16, R=a16, r32=1, o32=1) == -1                                                     # ... and gamma / beta
 
 
 def test_product_path_does_not_import_oracle():
