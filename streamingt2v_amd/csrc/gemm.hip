@@ -58,6 +58,42 @@ extern "C" int svd_gemm_config_valid(const svd_gemm_args* args, int cfg) {
     return SVD_EINVAL;
 }
 
+namespace {
+// the tile table is instantiated in four parts per element type (gemm_cfg.h)
+int dispatch(const svd_gemm_args& a, int cfg, hipStream_t s, int m_base) {
+    const bool f16 = a.dtype == SVD_DTYPE_F16;
+    if (!f16 && a.dtype != SVD_DTYPE_BF16) return SVD_EINVAL;
+    switch (cfg) {
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p0(a, cfg, s, m_base) : svd_gemm_launch_bf16_p0(a, cfg, s, m_base);
+        SVD_GEMM_CONFIGS_P0(X)
+#undef X
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p1(a, cfg, s, m_base) : svd_gemm_launch_bf16_p1(a, cfg, s, m_base);
+        SVD_GEMM_CONFIGS_P1(X)
+#undef X
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p2(a, cfg, s, m_base) : svd_gemm_launch_bf16_p2(a, cfg, s, m_base);
+        SVD_GEMM_CONFIGS_P2(X)
+#undef X
+#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p3(a, cfg, s, m_base) : svd_gemm_launch_bf16_p3(a, cfg, s, m_base);
+        SVD_GEMM_CONFIGS_P3(X)
+#undef X
+    }
+    return SVD_EINVAL;
+}
+}  // namespace
+
+// The tail of a launch (rows [m_base, a.M), gemm_impl.inc launch_kernel) with the smallest tile that carries these arguments: 128 x 128 first (cfg 1; BK = 32: cfg 5),
+// then 128-row tiles of the widths the stream / upsample kernels exist for.  SVD_EINVAL = none (the caller finishes the rows with its own tile).
+int svd_gemm_tail_launch_(const svd_gemm_args& a, int main_bm, int m_base, hipStream_t s) {
+    static const int prefer[] = {1, 5, 22, 4, 3};
+    for (int cfg : prefer) {
+        int bm = 0, bn = 0, th = 0, lds = 0;
+        if (svd_gemm_config_info(cfg, &bm, &bn, &th, &lds) != SVD_OK || bm >= main_bm || m_base % bm) continue;
+        if (svd_gemm_config_valid(&a, cfg) != 1) continue;
+        return dispatch(a, cfg, s, m_base);
+    }
+    return SVD_EINVAL;
+}
+
 extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
     if (!args) return SVD_EINVAL;
     const svd_gemm_args& a = *args;
@@ -102,23 +138,5 @@ extern "C" int svd_gemm(const svd_gemm_args* args, svd_stream_t stream) {
     if (a.tile_cfg > 0 && ((a.a_mode == SVD_A_CONV3X3 && a.ups) || a.res_f32 || a.out_mode == SVD_OUT_F32) && svd_gemm_config_valid(args, cfg) != 1)
         cfg = pick_cfg(a);   // a tile of a tuned table that does not carry the folded-upsample / fp32-stream kernel: the heuristic's pick does
     if (svd_gemm_config_valid(args, cfg) != 1) return SVD_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    // the tile table is instantiated in four parts per element type (gemm_cfg.h)
-    const bool f16 = a.dtype == SVD_DTYPE_F16;
-    if (!f16 && a.dtype != SVD_DTYPE_BF16) return SVD_EINVAL;
-    switch (cfg) {
-#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p0(a, cfg, s) : svd_gemm_launch_bf16_p0(a, cfg, s);
-        SVD_GEMM_CONFIGS_P0(X)
-#undef X
-#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p1(a, cfg, s) : svd_gemm_launch_bf16_p1(a, cfg, s);
-        SVD_GEMM_CONFIGS_P1(X)
-#undef X
-#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p2(a, cfg, s) : svd_gemm_launch_bf16_p2(a, cfg, s);
-        SVD_GEMM_CONFIGS_P2(X)
-#undef X
-#define X(id, bm_, bn_, wm, wn, bk, glds, tr, ns) case id: return f16 ? svd_gemm_launch_f16_p3(a, cfg, s) : svd_gemm_launch_bf16_p3(a, cfg, s);
-        SVD_GEMM_CONFIGS_P3(X)
-#undef X
-    }
-    return SVD_EINVAL;
+    return dispatch(a, cfg, (hipStream_t)stream, 0);
 }

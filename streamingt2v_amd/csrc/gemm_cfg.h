@@ -117,6 +117,10 @@ SVD_GEMM_CONFIGS(X)
 }  // namespace svd_gemm_detail
 
 // one per element type, defined in gemm_bf16.hip / gemm_f16.hip
-#define SVD_GEMM_DECL_PART(P) int svd_gemm_launch_bf16_p##P(const svd_gemm_args& a, int cfg, hipStream_t s); int svd_gemm_launch_f16_p##P(const svd_gemm_args& a, int cfg, hipStream_t s);
+// m_base (round 6): first row of the launch's window -- rows [m_base, a.M) of the problem are computed, all addressing stays absolute (the tail of a launch whose
+// last round would be nearly empty runs as a second launch with a smaller tile: svd_gemm_tail_launch_, gemm.hip)
+#define SVD_GEMM_DECL_PART(P) int svd_gemm_launch_bf16_p##P(const svd_gemm_args& a, int cfg, hipStream_t s, int m_base); int svd_gemm_launch_f16_p##P(const svd_gemm_args& a, int cfg, hipStream_t s, int m_base);
 SVD_GEMM_DECL_PART(0) SVD_GEMM_DECL_PART(1) SVD_GEMM_DECL_PART(2) SVD_GEMM_DECL_PART(3)
 #undef SVD_GEMM_DECL_PART
+// rows [m_base, a.M) with a tile smaller than `main_bm` rows (same bits: every tile configuration accumulates an output element in the same order); SVD_EINVAL if none fits
+int svd_gemm_tail_launch_(const svd_gemm_args& a, int main_bm, int m_base, hipStream_t s);

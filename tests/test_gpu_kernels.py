@@ -98,6 +98,60 @@ def test_gemm_w_panel_walk(ops, cfg, monkeypatch):
     check(f"gemm panel walk cfg{cfg} GEGLU vs fp32 torch", g1, h[:, :Hd] * F.gelu(h[:, Hd:]), 3e-2, 1e-2)
 
 
+@pytest.mark.parametrize("cfg", [8, 20, 21])
+def test_gemm_tail_split(ops, cfg, monkeypatch):
+    """Tail split of the persistent GEMM (csrc/gemm_impl.inc launch_kernel, round 6): when the last round of a launch holds only a few 256-row tiles, their rows run as
+    a second launch with a small tile.  Every tile configuration accumulates an output element in the same order, so the result must be BIT-IDENTICAL to the unsplit
+    launch (SVD_GEMM_TAIL=0; the split is opt-in, SVD_GEMM_TAIL=1: measured neutral on the job) -- plain GEMM with bias / per-frame vector / residual (16-bit and the fp32 stream), GEGLU, the 3x3-convolution and 3-tap temporal views,
+    a ragged last tile -- and equal to plain fp32 PyTorch.  Row counts: 1 032 and 520 tiles of 256 rows + a ragged rest (8 tiles past a multiple of 256 and of 512
+    resident workgroups, whichever the configuration has)."""
+    from streamingt2v_amd.video_model import pack_conv3x3, pack_geglu, pack_tconv3
+
+    def both(fn):
+        monkeypatch.setenv("SVD_GEMM_TAIL", "0")
+        a = fn()
+        monkeypatch.setenv("SVD_GEMM_TAIL", "1")
+        b = fn()
+        monkeypatch.delenv("SVD_GEMM_TAIL", raising=False)
+        assert torch.equal(a, b), "the tail split changes the bits"
+        return b
+
+    K, N, rpv = 320, 320, 2064
+    for M in (1032 * 256 - 37, 520 * 256 - 37):
+        a, w = rnd(M, K, seed=81), rnd(N, K, scale=K ** -0.5, seed=82)
+        bias = rnd(N, seed=83, dtype=torch.float32)
+        rowvec = rnd((M + rpv - 1) // rpv, N, seed=84, dtype=torch.float32)
+        R16, R32 = rnd(M, N, seed=85), rnd(M, N, seed=86, dtype=torch.float32)
+        ref = a.float() @ w.float().t() + bias + rowvec.repeat_interleave(rpv, 0)[:M]
+        o = both(lambda: ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_vec=rpv, residual=R16, tile_cfg=cfg))
+        check(f"gemm tail split cfg{cfg} M={M} 16-bit", o, ref + R16.float(), 3e-2, 1e-2)
+        o = both(lambda: ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_vec=rpv, residual=R32, out_f32=True, tile_cfg=cfg))
+        check(f"gemm tail split cfg{cfg} M={M} fp32 stream", o, ref + R32, 1e-2, 5e-3)
+    if cfg != 21:                                          # 320-wide tiles do not take the GEGLU epilogue
+        Hd = 640
+        w1 = rnd(2 * Hd, K, scale=K ** -0.5, seed=87).float().cpu()
+        b1 = rnd(2 * Hd, seed=88, dtype=torch.float32, scale=0.3).cpu()
+        w1p, b1p = pack_geglu(w1, b1)
+        w1p, b1p = w1p.to(BF16).cuda(), b1p.cuda()
+        g = both(lambda: ops.gemm(a, w1p, bias=b1p, geglu=True, tile_cfg=cfg))
+        h = a.float() @ w1.to(BF16).float().cuda().t() + b1.cuda()
+        check(f"gemm tail split cfg{cfg} GEGLU", g, h[:, :Hd] * F.gelu(h[:, Hd:]), 3e-2, 1e-2)
+    # 3x3 convolution view: 43 frames of 48 x 128 pixels = 264 192 rows = 1 032 tiles; 3-tap temporal view over the same rows (T = 43)
+    Fr, cin, cout, H, W = 43, 64, 320, 48, 128
+    x = rnd(Fr, cin, H, W, seed=89).float()
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=90).float()
+    cb = rnd(cout, seed=91, dtype=torch.float32)
+    tok = x.permute(0, 2, 3, 1).reshape(Fr * H * W, cin).to(BF16).contiguous()
+    wc = pack_conv3x3(wt).to(BF16).cuda()
+    o = both(lambda: ops.gemm(tok, wc, bias=cb, tile_cfg=cfg, conv=dict(cin=cin, hin=H, win=W, hout=H, wout=W, stride=1, ups=0, frames=Fr)))
+    check(f"conv3x3 tail split cfg{cfg}", o, F.conv2d(x, wt, cb, padding=1).permute(0, 2, 3, 1).reshape(-1, cout), 3e-2, 1e-2)
+    wt3 = rnd(cout, cin, 3, 1, 1, scale=(3 * cin) ** -0.5, seed=92).float()
+    w3 = pack_tconv3(wt3).to(BF16).cuda()
+    o = both(lambda: ops.gemm(tok, w3, bias=cb, temporal=dict(cin=cin, T=Fr, pix=H * W), tile_cfg=cfg))
+    xt = x.permute(1, 0, 2, 3).reshape(1, cin, Fr, H * W, 1)
+    check(f"temporal tail split cfg{cfg}", o, F.conv3d(xt, wt3, cb, padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0).reshape(-1, cout), 3e-2, 1e-2)
+
+
 def test_gemm_k32_and_f32_out(ops):
     M, N, K = 513, 132, 96
     a, w = rnd(M, K, seed=4), rnd(N, K, scale=K ** -0.5, seed=5)

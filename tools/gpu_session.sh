@@ -76,6 +76,8 @@ print(len(b), "signatures,", len(ch), "changed,", len([k for k in b if k not in 
 for k, x, y in ch[:40]: print("  ", k, x, "->", y)
 PY
               for v in gemm_tiles.json gemm_tiles_prev.json gemm_tiles.json gemm_tiles_prev.json; do SVD_GEMM_TILES=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --no-stages > $O/bench6_$v.out 2>/dev/null; echo "SVD_GEMM_TILES=$v"; cut -c1-120 $O/bench6_$v.out; done ;;
+    tailsplit) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "gemm" > $O/tailtest.log 2>&1; tail -3 $O/tailtest.log
+              for v in 1 0 1 0; do SVD_GEMM_TAIL=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace --no-stages > $O/bench6_tail$v.json 2>$O/bench6_tail$v.err; echo "SVD_GEMM_TAIL=$v"; cut -c1-120 $O/bench6_tail$v.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_tail$v.json; tail -1 $O/bench6_tail$v.err | cut -c1-200; done ;;
     svttests) timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stream_f32.py -m gpu -q -x -p no:cacheprovider > $O/svttests.log 2>&1; tail -4 $O/svttests.log ;;
     tailbench) for L in libsvdhip_pv_tail0.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-trace > $O/bench6_$L.json 2>/dev/null; echo $L; cut -c50-75 $O/bench6_$L.json; grep -o '"chunk0_s_mean": [0-9.]*, "ar_chunk_s_mean": [0-9.]*' $O/bench6_$L.json; done ;;
     geluab2)  for L in libsvdhip_pv_scalargelu.so libsvdhip.so libsvdhip_pv_scalargelu.so libsvdhip.so; do SVD_LIB_FILE=$L timeout 120 python tools/geglu_ab.py 30 2>&1 | tee -a $O/geglu_ab.txt; done ;;
